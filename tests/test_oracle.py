@@ -1,0 +1,320 @@
+"""Pin the CPU oracle (no GPU).
+
+The reference ships no golden vectors; what its own tests assert
+(`cggp/cg_test.py:12-77`) are closed-form identities.  They are reproduced here
+seeded and at much tighter tolerance, plus the cross-identities of SURVEY §8c.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import kernels as ok, cg as ocg, models as om, distance as od, cluster as oc
+
+RTOL = 1e-10
+
+
+def _problem(n=100, d=2, nsys=5, seed=0, name="se"):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    ls = rng.random(d) ** 2 + 0.5  # cg_test.py:21
+    kern = ok.Kernel(name, variance=1.3, lengthscales=ls)  # cg_test.py:22-24
+    A = om.add_diagonal(kern.K(X), 0.1 ** 2 * np.ones(n))  # cg_test.py:30-32
+    rhs = rng.standard_normal((n, nsys))
+    return X, kern, A, rhs
+
+
+# ------------------------------------------------------------------ known answers
+@pytest.mark.parametrize("name,expect", [
+    ("se", np.exp(-0.5)),
+    ("matern12", np.exp(-1.0)),
+    ("matern32", (1 + np.sqrt(3)) * np.exp(-np.sqrt(3))),
+    ("matern52", (1 + np.sqrt(5) + 5.0 / 3.0) * np.exp(-np.sqrt(5))),
+])
+def test_kernel_known_answers(name, expect):
+    k = ok.Kernel(name, variance=2.0, lengthscales=1.0)
+    K = k.K(np.array([[0.0]]), np.array([[1.0], [0.0]]))
+    assert np.allclose(K[0, 0], 2.0 * expect, rtol=1e-15)
+    assert np.allclose(K[0, 1], 2.0, rtol=1e-15)  # r=0 -> variance
+    # lengthscale 2 at distance 2 is the same point in scaled space
+    k2 = ok.Kernel(name, variance=2.0, lengthscales=2.0)
+    assert np.allclose(k2.K(np.array([[0.0]]), np.array([[2.0]]))[0, 0], 2.0 * expect, rtol=1e-15)
+
+
+@pytest.mark.parametrize("name", ok.KERNEL_NAMES)
+def test_kernel_two_restatements_agree(name):
+    rng = np.random.default_rng(1)
+    X, Z = rng.standard_normal((50, 3)), rng.standard_normal((20, 3))
+    k = ok.Kernel(name, variance=0.7, lengthscales=[0.5, 1.0, 2.0])
+    K = k.K(X, Z)
+    # matern12 is only Lipschitz at r=0; everything here has r >> 0
+    assert np.allclose(K, ok.k_direct(k, X, Z), rtol=1e-11, atol=1e-13)
+    Kxx = k.K(X)
+    assert np.allclose(Kxx, Kxx.T, atol=1e-14)
+    assert np.linalg.eigvalsh(Kxx).min() > -1e-10
+    assert np.allclose(ok.Kuf(Z, k, X), K.T, rtol=1e-13)
+    assert np.allclose(np.diag(ok.Kuu(Z, k, 1e-3)), 0.7 + 1e-3)
+    assert np.all(k.K_diag(X) == k.variance)
+
+
+def test_add_diagonal():
+    A = np.arange(9.0).reshape(3, 3)
+    out = om.add_diagonal(A, np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(out, A + np.diag([1.0, 2.0, 3.0]))
+    assert np.array_equal(A, np.arange(9.0).reshape(3, 3))  # not in place
+
+
+# ------------------------------------------------------------------ cg_test.py::test_cg
+def test_cg_matches_direct_solve_reference_config():
+    """cg_test.py:12-46 with its own parameters (thr=1e-12, cap = n iterations)."""
+    X, kern, A, rhs = _problem()
+    cg = ocg.ConjugateGradient(1e-12)
+    sol, (steps, err) = cg.solve_with_stats(A, rhs)
+    ref = np.linalg.solve(A, rhs)
+    # the reference tolerance (rtol=1e-3, atol=1e-4) ...
+    np.testing.assert_allclose(sol, ref, rtol=1e-3, atol=1e-4)
+    assert steps <= 100 and err.shape == (5, 1)
+
+
+def test_cg_matches_direct_solve_tight():
+    """Same identity, seeded and tightened (1e-8; the guards bound what CG can reach)."""
+    X, kern, A, rhs = _problem()
+    cg = ocg.ConjugateGradient(1e-16, max_iterations=2000)
+    sol = cg(A, rhs)
+    ref = np.linalg.solve(A, rhs)
+    assert np.max(np.abs(sol - ref)) / np.max(np.abs(ref)) < 1e-8
+    # The reference's breakdown guards (gamma = 0 where p.Ap <= 1e-16, beta-term = 0 where
+    # rz <= 1e-16; conjugate_gradient.py:68,79) freeze the iteration once 0.5||r||^2 is
+    # ~1e-17: thresholds below that run to the cap without further progress.
+    sol_lo, (steps, err) = ocg.ConjugateGradient(1e-26, max_iterations=400).solve_with_stats(A, rhs)
+    assert steps == 400 and 1e-19 < err.max() < 1e-15
+    assert np.allclose(sol_lo, sol, rtol=0, atol=1e-7)
+
+
+def test_cg_function_level_layout_and_stats():
+    X, kern, A, rhs = _problem(n=40)
+    sol, (steps, err) = ocg.conjugate_gradient(A, rhs.T, np.zeros_like(rhs.T), 1e-16,
+                                               max_iterations=500)
+    assert sol.shape == (5, 40) and err.shape == (5, 1) and 0 < steps <= 500
+    r = rhs.T - sol @ A
+    # stats_error is 0.5 * rz of the recurrence residual (Eye: rz = ||r||^2)
+    assert np.all(0.5 * np.sum(r * r, -1) < 2e-16)
+    assert np.all(err[:, 0] <= 1e-16)
+
+
+def test_cg_iteration_cap_and_any_criterion():
+    X, kern, A, rhs = _problem(n=60)
+    sol, (steps, _) = ocg.conjugate_gradient(A, rhs.T, np.zeros_like(rhs.T), 0.0,
+                                             max_iterations=7)
+    assert steps == 7
+    # "any": an already-solved RHS does not stop the others
+    rhs2 = rhs.T.copy()
+    rhs2[0] = 0.0
+    _, (steps2, err2) = ocg.conjugate_gradient(A, rhs2, np.zeros_like(rhs2), 1e-12,
+                                               max_iterations=500)
+    assert steps2 > 1 and err2[0, 0] == 0.0
+
+
+def test_cg_zero_rhs_takes_no_step_and_guards():
+    X, kern, A, rhs = _problem(n=30)
+    z = np.zeros((2, 30))
+    sol, (steps, err) = ocg.conjugate_gradient(A, z, z.copy(), 1e-6)
+    assert steps == 0 and np.all(sol == 0) and np.all(err == 0)
+    # denom <= 1e-16 -> gamma = 0 (cg :68): a zero RHS next to a live one stays exactly zero
+    b = np.vstack([np.zeros(30), rhs[:30, 0]])
+    sol, _ = ocg.conjugate_gradient(A, b, np.zeros_like(b), 1e-16, max_iterations=300)
+    assert np.all(sol[0] == 0.0) and np.all(np.isfinite(sol))
+
+
+def test_cg_initial_solution_and_cycle_refresh():
+    X, kern, A, rhs = _problem(n=50)
+    ref = np.linalg.solve(A, rhs)
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=1500, max_steps_cycle=10, min_float=1e-300)
+    sol = cg(A, rhs, initial_solution=ref + 1e-3)
+    assert np.max(np.abs(sol - ref)) < 1e-8
+    # exact start: zero steps
+    _, (steps, _) = ocg.ConjugateGradient(1e-10).solve_with_stats(A, rhs, initial_solution=ref)
+    assert steps == 0
+
+
+@pytest.mark.parametrize("pre", ["jacobi", "block"])
+def test_cg_preconditioners(pre):
+    X, kern, A, rhs = _problem(n=64)
+    if pre == "jacobi":
+        P = ocg.JacobiPreconditioner()
+    else:
+        P = ocg.BlockPreconditioner(np.arange(64).reshape(8, 8))
+    cg = ocg.ConjugateGradient(1e-26, preconditioner=P, max_iterations=3000, min_float=1e-300)
+    sol = cg(A, rhs)
+    ref = np.linalg.solve(A, rhs)
+    assert np.max(np.abs(sol - ref)) / np.max(np.abs(ref)) < 1e-9
+
+
+def test_cg_custom_gradient_matches_solve_gradient():
+    """cg_test.py:34-46: d(sum CG(A,b)) == d(sum solve(A,b)), here in closed form.
+
+    For f = sum(A^-1 B): dB = A^-1 1, dA = -(A^-1 1)(A^-1 B)^T (A symmetric).
+    """
+    X, kern, A, rhs = _problem(n=40)
+    thr = 1e-26
+    sol, _ = ocg.conjugate_gradient(A, rhs.T, np.zeros_like(rhs.T), thr, max_iterations=2000,
+                                    min_float=1e-300)
+    dx = np.ones_like(sol)
+    dA, db = ocg.conjugate_gradient_vjp(A, sol, dx, thr, max_iterations=2000, min_float=1e-300)
+    Ainv1 = np.linalg.solve(A, np.ones((40, 5)))
+    ref_dB = Ainv1.T
+    ref_dA = -np.linalg.solve(A, rhs) @ Ainv1.T
+    assert np.allclose(db, ref_dB, rtol=1e-9, atol=1e-10)
+    assert np.allclose(dA, ref_dA, rtol=1e-8, atol=1e-8)
+    # finite-difference check through the kernel variance (the reference differentiates
+    # w.r.t. kernel parameters): d/dvar sum(solve(var*K0 + s I, B)) = sum(dA * K0)
+    K0 = kern.K(X) / kern.variance
+    h = 1e-6
+    f = lambda v: np.sum(np.linalg.solve(om.add_diagonal(v * K0, 0.01 * np.ones(40)), rhs))
+    fd = (f(1.3 + h) - f(1.3 - h)) / (2 * h)
+    assert np.isclose(np.sum(dA * K0), fd, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ cg_test.py::test_log_determinant_grad
+def test_eval_logdet_forward_zero_and_grad():
+    X, kern, A, rhs = _problem(n=50)
+    assert om.eval_logdet_forward(A) == 0.0  # cg_test.py:74
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=3000, min_float=1e-300)
+    G = om.eval_logdet_grad(A, cg)
+    assert np.allclose(G, np.linalg.inv(A), rtol=1e-8, atol=1e-8)  # d logdet / dA = A^-T
+    # probes = +-basis, P = n  -> (1/n) A^-1 Zp Zp^T = A^-1 when Zp = sqrt(n) * I-like; use
+    # orthogonal +-1 columns (Hadamard) so Zp Zp^T = n I and the estimator is exact.
+    n = 64
+    X, kern, A, _ = _problem(n=n)
+    H = np.array([[1.0]])
+    while H.shape[0] < n:
+        H = np.block([[H, H], [H, -H]])
+    G = om.eval_logdet_grad(A, cg, df=2.0, probes=H)
+    assert np.allclose(G, 2.0 * np.linalg.inv(A), rtol=1e-7, atol=1e-7)
+
+
+# ------------------------------------------------------------------ model identities
+def _model(name="se", N=300, D=2, M=24, seed=3):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    y = np.sin(X).sum(1, keepdims=True) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.choice(N, M, replace=False)]
+    kern = ok.Kernel(name, variance=1.1, lengthscales=[0.9, 1.3][:D] if D <= 2 else 1.0)
+    idx = oc.nearest_centre_sqdist(Z, X)
+    u, counts = oc.cluster_stats(idx, y, M)
+    return X, y, Z, kern, u, counts
+
+
+@pytest.mark.parametrize("name", ok.KERNEL_NAMES)
+def test_cggp_predict_matches_cholesky_twin(name):
+    X, y, Z, kern, u, counts = _model(name)
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=5000, min_float=1e-300)
+    tw = om.ClusterGP(kern, 0.1, Z, pseudo_u=u, cluster_counts=counts)
+    m = om.CGGP(kern, 0.1, Z, cg, num_probes=None, pseudo_u=u, cluster_counts=counts)
+    Xs = X[:57]
+    mu0, v0 = tw.predict_f(Xs)
+    mu1, v1 = m.predict_f(Xs)
+    assert mu1.shape == (57, 1) and v1.shape == (57, 1)
+    assert np.allclose(mu1, mu0, rtol=1e-8, atol=1e-10)
+    assert np.allclose(v1, v0, rtol=1e-8, atol=1e-10)
+    c0 = tw.predict_f(Xs[:9], full_cov=True)[1]
+    c1 = m.predict_f(Xs[:9], full_cov=True)[1]
+    assert c1.shape == (1, 9, 9) and np.allclose(c1, c0, rtol=1e-8, atol=1e-10)
+    assert np.allclose(m.q_moments()[0], tw.q_moments()[0], rtol=1e-8, atol=1e-10)
+
+
+def test_cggp_prior_kl_exact_trace_omits_logdet():
+    X, y, Z, kern, u, counts = _model()
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=5000, min_float=1e-300)
+    tw = om.ClusterGP(kern, 0.1, Z, pseudo_u=u, cluster_counts=counts)
+    m = om.CGGP(kern, 0.1, Z, cg, num_probes=None, pseudo_u=u, cluster_counts=counts)
+    Kmm, KL = tw._KmmLambda()
+    logdet = np.linalg.slogdet(KL)[1]
+    # CGGP's value omits log|Kmm+Lambda| (models.py:46,319): twin - 0.5*logdet
+    assert np.isclose(m.prior_kl(), tw.prior_kl() - 0.5 * logdet, rtol=1e-9)
+    e_tw = tw.elbo((X[:40], y[:40]))
+    e_cg = m.elbo((X[:40], y[:40]))
+    assert np.isclose(e_cg, e_tw + 0.5 * logdet, rtol=1e-9)
+
+
+def test_hutchinson_trace_definition_and_exact_limit():
+    X, y, Z, kern, u, counts = _model(M=32)
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=5000, min_float=1e-300)
+    tw = om.ClusterGP(kern, 0.1, Z, pseudo_u=u, cluster_counts=counts)
+    Kmm, KL = tw._KmmLambda()
+    exact = np.trace(np.linalg.solve(KL, Kmm))
+    probes = om.rademacher(32, 7, seed=4)
+    assert set(np.unique(probes)) == {-1.0, 1.0}
+    est = om.hutchinson_trace(KL, Kmm, probes, cg)
+    direct = np.sum(np.linalg.solve(KL, probes) * (Kmm @ probes)) / 7
+    assert np.isclose(est, direct, rtol=1e-9)
+    H = np.array([[1.0]])
+    while H.shape[0] < 32:
+        H = np.block([[H, H], [H, -H]])
+    assert np.isclose(om.hutchinson_trace(KL, Kmm, H, cg), exact, rtol=1e-9)
+    m = om.CGGP(kern, 0.1, Z, cg, num_probes=32, pseudo_u=u, cluster_counts=counts)
+    m0 = om.CGGP(kern, 0.1, Z, cg, num_probes=None, pseudo_u=u, cluster_counts=counts)
+    assert np.isclose(m.prior_kl(probes=H), m0.prior_kl(), rtol=1e-9)
+
+
+def test_sgpr_cg_matches_two_cholesky_closed_form():
+    X, y, Z, kern, u, counts = _model(N=400, M=20)
+    cg = ocg.ConjugateGradient(1e-26, max_iterations=20000, min_float=1e-300)
+    ref = om.SGPR((X, y), kern, Z, 0.1, jitter=1e-6)
+    alt = om.SGPRCG((X, y), kern, Z, 0.1, cg, jitter=1e-6)
+    Xs = X[:33] + 0.1
+    mu0, v0 = ref.predict_f(Xs)
+    mu1, v1 = alt.predict_f(Xs)
+    assert np.allclose(mu1, mu0, rtol=1e-6, atol=1e-8)
+    assert np.allclose(v1, v0, rtol=1e-6, atol=1e-8)
+    assert np.isfinite(ref.elbo())
+    op = alt.op
+    assert np.allclose(op.dense(), op.dense().T)
+    V = np.random.default_rng(0).standard_normal((20, 3))
+    assert np.allclose(op.matmul(V), op.dense() @ V, rtol=1e-12)
+    assert np.allclose(op.diag(), np.diag(op.dense()), rtol=1e-12)
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+def test_shard_sum_invariance(G):
+    """row-sharded partial products sum to the unsharded product."""
+    X, y, Z, kern, u, counts = _model(N=1000, M=16)
+    V = np.random.default_rng(0).standard_normal((16, 2))
+    full = om.SgprNormalOperator(X, Z, kern, 0.1).matmul(V)
+    shard = om.SgprNormalOperator(X, Z, kern, 0.1, shards=G).matmul(V)
+    assert np.max(np.abs(full - shard)) / np.max(np.abs(full)) < 1e-12
+
+
+def test_distance_functions():
+    rng = np.random.default_rng(0)
+    x, yv = rng.standard_normal((5, 3)), rng.standard_normal((5, 3))
+    kern = ok.Kernel("matern32", variance=1.7, lengthscales=0.8)
+    assert np.allclose(od.euclid_distance((x, yv)), np.sqrt(((x - yv) ** 2).sum(-1)))
+    kxy = np.diag(kern.K(x, yv))
+    assert np.allclose(od.create_distance_fn(kern, "covariance")((x, yv)), 2 * 1.7 - 2 * kxy)
+    assert np.allclose(od.create_distance_fn(kern, "correlation")((x, yv)), 1 - kxy / 1.7)
+    assert od.create_distance_fn(kern, "euclidean") is od.euclid_distance
+
+
+def test_cluster_stats():
+    Z = np.array([[0.0], [10.0], [100.0]])
+    X = np.array([[1.0], [-1.0], [9.0], [4.9]])
+    y = np.array([[1.0], [3.0], [5.0], [7.0]])
+    idx = oc.nearest_centre_sqdist(Z, X)
+    assert idx.tolist() == [0, 0, 1, 0]
+    i2, d2 = oc.nearest_centre(Z, X, od.euclid_distance)
+    assert i2.tolist() == idx.tolist() and np.allclose(d2, [1, 1, 1, 4.9])
+    u, c = oc.cluster_stats(idx, y, 3)
+    assert np.allclose(u[:2, 0], [11.0 / 3, 5.0]) and np.isnan(u[2, 0])
+    assert c[:, 0].tolist() == [3.0, 1.0, 1.0]  # empty -> 1 (optimize.py:70)
+    u2, c2 = oc.cluster_stats(idx, y, 3, empty="nan")
+    assert c2[2, 0] == 0.0
+
+
+def test_likelihood_and_metrics_closed_form():
+    mu, var, y = np.array([[0.5]]), np.array([[0.2]]), np.array([[1.0]])
+    ve = om.gaussian_variational_expectations(mu, var, y, 0.1)
+    assert np.isclose(ve[0], -0.5 * np.log(2 * np.pi) - 0.5 * np.log(0.1) - 0.5 * (0.25 + 0.2) / 0.1)
+    ld = om.gaussian_predict_log_density(mu, var, y, 0.1)
+    assert np.isclose(ld[0], -0.5 * (np.log(2 * np.pi) + np.log(0.3) + 0.25 / 0.3))
+    rmse, nlpd = om.rmse_nlpd(mu, var, y, 0.1)
+    assert np.isclose(rmse, 0.5) and np.isclose(nlpd, -ld[0])
