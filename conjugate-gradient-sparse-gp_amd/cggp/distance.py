@@ -1,0 +1,51 @@
+"""Pairwise distance functions -- host mirror of `cggp/distance.py` (rows D1-D3).
+
+`create_distance_fn(kernel, distance_type)` returns `fn((x, y))` exactly as the reference's
+does (`cggp/distance.py:14-34`); x and y broadcast over leading axes.  These are the eager,
+elementwise forms used on a handful of points; the N x M nearest-centre search built on the
+same distances runs fused in libmgp (`ops.nearest_center`, row F1).
+"""
+
+import math
+
+import torch
+
+DistanceTypes = ("euclidean", "covariance", "correlation")
+
+
+def euclid_distance(args):
+    """`cggp/distance.py:9-11`."""
+    x, y = args
+    return torch.linalg.norm(x - y, dim=-1)
+
+
+def _rho(kernel, x, y):
+    """k(x,y)/variance for matching rows, through GPflow's expansion of the scaled distance."""
+    ls = torch.as_tensor(kernel.lengthscales, dtype=x.dtype, device=x.device)
+    a, b = x / ls, y / ls
+    r2 = (a * a).sum(-1) + (b * b).sum(-1) - 2.0 * (a * b).sum(-1)
+    if kernel.name == "se":
+        return torch.exp(-0.5 * r2)
+    r = torch.sqrt(torch.clamp(r2, min=1e-36))
+    if kernel.name == "matern12":
+        return torch.exp(-r)
+    if kernel.name == "matern32":
+        s3 = math.sqrt(3.0)
+        return (1.0 + s3 * r) * torch.exp(-s3 * r)
+    s5 = math.sqrt(5.0)
+    return (1.0 + s5 * r + 5.0 / 3.0 * r * r) * torch.exp(-s5 * r)
+
+
+def create_distance_fn(kernel, distance_type):
+    def cov(args):  # :15-22
+        x, y = args
+        kxy = kernel.variance * _rho(kernel, x, y)
+        return kernel.variance + kernel.variance - 2 * kxy
+
+    def cor(args):  # :24-30
+        x, y = args
+        kxy = kernel.variance * _rho(kernel, x, y)
+        return 1.0 - kxy / math.sqrt(kernel.variance * kernel.variance)
+
+    functions = {"covariance": cov, "correlation": cor, "euclidean": euclid_distance}
+    return functions[distance_type]

@@ -1,0 +1,199 @@
+"""Tensor-level wrappers over the C ABI (include/mgp.h).  No arithmetic happens here.
+
+Every function takes CUDA(HIP) torch tensors, validates shapes on the host (the kernels
+assume them) and enqueues libmgp work on torch's current stream.
+"""
+
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import COLS, ROWS  # noqa: F401
+
+
+class KernelSpec:
+    """Host-side kernel hyper-parameters in the form libmgp takes them (row K2)."""
+
+    def __init__(self, kind, variance, lengthscales, D):
+        self.kind = kind
+        self.variance = float(variance)
+        ls = [float(x) for x in (lengthscales if hasattr(lengthscales, "__len__") else [lengthscales])]
+        self.lengthscales = ls * D if len(ls) == 1 else ls
+        self.D = int(D)
+        if len(self.lengthscales) != self.D:
+            raise ValueError(f"lengthscales has {len(self.lengthscales)} entries, inputs have D={self.D}")
+
+    def struct(self, dtype_c):
+        return _hip.make_kernel_struct(self.kind, dtype_c, self.D, self.variance, self.lengthscales)
+
+
+def _points(t, name, D=None, dtype=None):
+    t = _hip.check_tensor(t, name, dtype=dtype)
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be [n, D], got {tuple(t.shape)}")
+    if D is not None and t.shape[1] != D:
+        raise ValueError(f"{name} has D={t.shape[1]}, expected {D}")
+    return t
+
+
+def knm_matvec(spec, X, Z, V, v_layout=COLS, out_layout=None):
+    """out = k(X, Z) @ V.  V [M,R] (COLS) or [R,M] (ROWS); out [N,R] or [R,N]."""
+    X = _points(X, "X", spec.D)
+    Z = _points(Z, "Z", spec.D, X.dtype)
+    V = _hip.check_tensor(V, "V", dtype=X.dtype)
+    if V.dim() != 2:
+        raise ValueError("V must be 2-D")
+    M = Z.shape[0]
+    R = V.shape[1] if v_layout == COLS else V.shape[0]
+    if (V.shape[0] if v_layout == COLS else V.shape[1]) != M:
+        raise ValueError(f"V shape {tuple(V.shape)} does not match M={M}")
+    out_layout = v_layout if out_layout is None else out_layout
+    N = X.shape[0]
+    out = torch.empty((N, R) if out_layout == COLS else (R, N), dtype=X.dtype, device=X.device)
+    if N == 0 or R == 0:
+        return out
+    if M == 0:
+        return out.zero_()
+    hd = _hip.get_handle(X.device)
+    k = spec.struct(_hip.dtype_code(X))
+    hd.check(hd.lib.mgp_knm_matvec(hd.h, ctypes.byref(k), _hip.ptr(X), N, _hip.ptr(Z), M, _hip.ptr(V), R,
+                                   v_layout, _hip.ptr(out), out_layout))
+    return out
+
+
+def kmn_matvec(spec, X, Z, W, w_layout=COLS, out_layout=None):
+    """out = k(Z, X) @ W = K_nm^T W.  W [N,R] (COLS) or [R,N] (ROWS); out [M,R] or [R,M]."""
+    X = _points(X, "X", spec.D)
+    Z = _points(Z, "Z", spec.D, X.dtype)
+    W = _hip.check_tensor(W, "W", dtype=X.dtype)
+    if W.dim() != 2:
+        raise ValueError("W must be 2-D")
+    N, M = X.shape[0], Z.shape[0]
+    R = W.shape[1] if w_layout == COLS else W.shape[0]
+    if (W.shape[0] if w_layout == COLS else W.shape[1]) != N:
+        raise ValueError(f"W shape {tuple(W.shape)} does not match N={N}")
+    out_layout = w_layout if out_layout is None else out_layout
+    out = torch.empty((M, R) if out_layout == COLS else (R, M), dtype=X.dtype, device=X.device)
+    if M == 0 or R == 0:
+        return out
+    if N == 0:
+        return out.zero_()
+    hd = _hip.get_handle(X.device)
+    k = spec.struct(_hip.dtype_code(X))
+    hd.check(hd.lib.mgp_kmn_matvec(hd.h, ctypes.byref(k), _hip.ptr(X), N, _hip.ptr(Z), M, _hip.ptr(W), R,
+                                   w_layout, _hip.ptr(out), out_layout))
+    return out
+
+
+def k_dense(spec, A, B, jitter=0.0, diag_add=None):
+    """out [na, nb] = k(A, B) (+ jitter I) (+ diag(diag_add)); the diagonal terms need na == nb."""
+    A = _points(A, "A", spec.D)
+    B = _points(B, "B", spec.D, A.dtype)
+    na, nb = A.shape[0], B.shape[0]
+    if (jitter != 0.0 or diag_add is not None) and na != nb:
+        raise ValueError("diagonal terms need a square block")
+    if diag_add is not None:
+        diag_add = _hip.check_tensor(diag_add, "diag_add", dtype=A.dtype).reshape(-1)
+        if diag_add.shape[0] != na:
+            raise ValueError("diag_add length mismatch")
+    out = torch.empty((na, nb), dtype=A.dtype, device=A.device)
+    if na == 0 or nb == 0:
+        return out
+    hd = _hip.get_handle(A.device)
+    k = spec.struct(_hip.dtype_code(A))
+    hd.check(hd.lib.mgp_k_dense(hd.h, ctypes.byref(k), _hip.ptr(A), na, _hip.ptr(B), nb, _hip.ptr(out), nb,
+                                float(jitter), _hip.ptr(diag_add)))
+    return out
+
+
+def kmn_knm(spec, X, Z):
+    """out [M,M] = k(Z,X) k(X,Z) on the matrix cores (row S1)."""
+    X = _points(X, "X", spec.D)
+    Z = _points(Z, "Z", spec.D, X.dtype)
+    M = Z.shape[0]
+    out = torch.empty((M, M), dtype=X.dtype, device=X.device)
+    if M == 0:
+        return out
+    hd = _hip.get_handle(X.device)
+    k = spec.struct(_hip.dtype_code(X))
+    hd.check(hd.lib.mgp_kmn_knm(hd.h, ctypes.byref(k), _hip.ptr(X), X.shape[0], _hip.ptr(Z), M, _hip.ptr(out)))
+    return out
+
+
+def symm_matmul(A, P):
+    """out [Bt,n] = P [Bt,n] @ A [n,n] for symmetric A (row M2)."""
+    A = _hip.check_tensor(A, "A")
+    P = _hip.check_tensor(P, "P", dtype=A.dtype)
+    if A.dim() != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("A must be square")
+    if P.dim() != 2 or P.shape[1] != A.shape[0]:
+        raise ValueError(f"P shape {tuple(P.shape)} does not match n={A.shape[0]}")
+    out = torch.empty_like(P)
+    if P.numel() == 0:
+        return out
+    hd = _hip.get_handle(A.device)
+    hd.check(hd.lib.mgp_symm_matmul(hd.h, _hip.dtype_code(A), _hip.ptr(A), A.shape[0], _hip.ptr(P), P.shape[0],
+                                    _hip.ptr(out)))
+    return out
+
+
+def colwise_dot(A, B):
+    """out [cols] = sum over rows of A*B (tf.reduce_sum(A * B, axis=0), models.py:343)."""
+    A = _hip.check_tensor(A, "A")
+    B = _hip.check_tensor(B, "B", dtype=A.dtype, shape=tuple(A.shape))
+    if A.dim() != 2:
+        raise ValueError("A must be 2-D")
+    out = torch.empty((A.shape[1],), dtype=A.dtype, device=A.device)
+    if A.shape[1] == 0:
+        return out
+    hd = _hip.get_handle(A.device)
+    hd.check(hd.lib.mgp_colwise_dot(hd.h, _hip.dtype_code(A), _hip.ptr(A), _hip.ptr(B), A.shape[0], A.shape[1],
+                                    _hip.ptr(out)))
+    return out
+
+
+def dot_all(A, B):
+    """float(sum(A*B)) accumulated in fp64 (Hutchinson trace, models.py:313)."""
+    A = _hip.check_tensor(A, "A")
+    B = _hip.check_tensor(B, "B", dtype=A.dtype)
+    if A.numel() != B.numel():
+        raise ValueError("size mismatch")
+    hd = _hip.get_handle(A.device)
+    out = ctypes.c_double(0.0)
+    hd.check(hd.lib.mgp_dot_all(hd.h, _hip.dtype_code(A), _hip.ptr(A), _hip.ptr(B), A.numel(), ctypes.byref(out)))
+    return out.value
+
+
+DIST_TYPES = {"sqeuclidean": 0, "euclidean": 1, "covariance": 2, "correlation": 3}
+
+
+def nearest_center(spec, X, Z, distance_type="sqeuclidean", return_distance=True):
+    """idx [N] int64 = argmin_m d(Z_m, X_i); optional best distance [N] (row F1)."""
+    X = _points(X, "X", spec.D)
+    Z = _points(Z, "Z", spec.D, X.dtype)
+    if Z.shape[0] == 0:
+        raise ValueError("need at least one centre")
+    N = X.shape[0]
+    idx = torch.empty((N,), dtype=torch.int64, device=X.device)
+    best = torch.empty((N,), dtype=X.dtype, device=X.device) if return_distance else None
+    if N > 0:
+        hd = _hip.get_handle(X.device)
+        k = spec.struct(_hip.dtype_code(X))
+        hd.check(hd.lib.mgp_nearest_center(hd.h, ctypes.byref(k), DIST_TYPES[distance_type], _hip.ptr(X), N,
+                                           _hip.ptr(Z), Z.shape[0], _hip.ptr(idx), _hip.ptr(best)))
+    return (idx, best) if return_distance else idx
+
+
+def cluster_stats(idx, y, M):
+    """(sums [M], counts [M]) of y per cluster, deterministic order."""
+    idx = _hip.check_tensor(idx, "idx", dtype=torch.int64).reshape(-1)
+    y = _hip.check_tensor(y, "y").reshape(-1)
+    if idx.shape[0] != y.shape[0]:
+        raise ValueError("idx / y length mismatch")
+    sums = torch.empty((M,), dtype=y.dtype, device=y.device)
+    counts = torch.empty((M,), dtype=y.dtype, device=y.device)
+    hd = _hip.get_handle(y.device)
+    hd.check(hd.lib.mgp_cluster_stats(hd.h, _hip.dtype_code(y), _hip.ptr(idx), _hip.ptr(y), y.shape[0], M,
+                                      _hip.ptr(sums), _hip.ptr(counts)))
+    return sums, counts

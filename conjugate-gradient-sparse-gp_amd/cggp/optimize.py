@@ -1,0 +1,50 @@
+"""Inducing-parameter updates (next row F1) -- host mirror of `cggp/optimize.py:41-98`.
+
+Given centres Z: assign every input to its nearest centre, pseudo_u = per-cluster mean of y,
+counts = per-cluster size (-> Lambda = sigma^2 / counts, `cggp/models.py:226-228`).  The N x M
+search and the per-cluster sums run fused in libmgp; with row-sharded data the [M] sums and
+counts are summed over ranks by one all-reduce.
+"""
+
+import torch
+
+from . import ops
+
+
+def nearest_centre_statistics(kernel, Z, data, distance_type="sqeuclidean", allreduce=None):
+    """(idx [N], sums [M], counts [M]) for this rank's rows."""
+    x, y = data
+    spec = kernel.spec(Z.shape[1])
+    idx = ops.nearest_center(spec, x, Z, distance_type=distance_type, return_distance=False)
+    sums, counts = ops.cluster_stats(idx, y, Z.shape[0])
+    if allreduce is not None:
+        both = torch.stack([sums, counts])
+        allreduce(both.view(-1))
+        sums, counts = both[0], both[1]
+    return idx, sums, counts
+
+
+def oips_update_inducing_parameters(model, data, Z, allreduce=None):
+    """`optimize.py:41-78` with the centres given: square_distance argmin, empty clusters get
+    count 1 (:70) and keep the reference's NaN mean (reduce_mean of nothing)."""
+    _, sums, counts = nearest_centre_statistics(model.kernel, Z, data, "sqeuclidean", allreduce)
+    means = sums / counts  # 0/0 -> NaN, as tf.reduce_mean of an empty selection
+    new_counts = torch.where(counts != 0, counts, torch.ones_like(counts))
+    return Z, means[:, None], new_counts[:, None]
+
+
+def kmeans_update_inducing_parameters(model, data, distance_type, Z, allreduce=None):
+    """`optimize.py:81-98`: u = scatter_add(y) / counts, counts kept as they are."""
+    dt = {"euclidean": "euclidean", "covariance": "covariance", "correlation": "correlation",
+          None: "euclidean"}[distance_type]
+    _, sums, counts = nearest_centre_statistics(model.kernel, Z, data, dt, allreduce)
+    return Z, (sums / counts)[:, None], counts[:, None]
+
+
+def assign_inducing_parameters(model, iv, means, counts):
+    """`create_model_and_update_fn.update_fn` (`cggp/cli_utils.py:394-411`)."""
+    model.inducing_variable.Z = iv.to(model.inducing_variable.Z.dtype)
+    if hasattr(model, "pseudo_u"):
+        model.pseudo_u = means.to(model.pseudo_u.dtype)
+        model.cluster_counts = counts.to(model.cluster_counts.dtype)
+    return iv, means, counts

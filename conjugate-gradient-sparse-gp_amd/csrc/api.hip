@@ -1,0 +1,128 @@
+// api.hip -- handle lifecycle and the small reductions of the model surface.
+#include "mgp_common.h"
+
+extern "C" int mgp_version(void) { return MGP_VERSION; }
+
+extern "C" const char* mgp_build_arch(void) { return "gfx950"; }
+
+extern "C" int mgp_create(mgp_handle** out, int device) {
+  if (!out) return MGP_E_BADARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MGP_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return MGP_E_HIP;
+  mgp_handle* h = new (std::nothrow) mgp_handle();
+  if (!h) return MGP_E_NOMEM;
+  h->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+  if (hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault) != hipSuccess) {
+    delete h;
+    return MGP_E_NOMEM;
+  }
+  *out = h;
+  return MGP_OK;
+}
+
+extern "C" int mgp_destroy(mgp_handle* h) {
+  if (!h) return MGP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->cg) (void)hipFree(h->cg);
+  if (h->opws) (void)hipFree(h->opws);
+  if (h->host_flag) (void)hipHostFree(h->host_flag);
+  delete h;
+  return MGP_OK;
+}
+
+extern "C" int mgp_set_stream(mgp_handle* h, void* hip_stream) {
+  if (!h) return MGP_E_BADARG;
+  h->stream = (hipStream_t)hip_stream;
+  return MGP_OK;
+}
+
+extern "C" const char* mgp_last_error(mgp_handle* h) { return h ? h->err : "invalid handle"; }
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// out[c] = sum_r A[r,c]*B[r,c]: block = 64 columns x 4 row-slices, rows summed in fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void colwise_dot_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                          long rows, long cols, T* __restrict__ out) {
+  __shared__ T red[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + lane;
+  T s = 0;
+  if (c < cols)
+    for (long r = slice; r < rows; r += 4) s = mgp_fma(A[r * cols + c], B[r * cols + c], s);
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// stage 1 of sum(A*B): one partial per block
+template <typename T>
+__global__ __launch_bounds__(256) void dot_partial_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                          long count, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256)
+    s += (double)A[i] * (double)B[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int mgp_colwise_dot(mgp_handle* h, int dtype, const void* A, const void* B, int64_t rows,
+                               int64_t cols, void* out) {
+  if (!h) return MGP_E_BADARG;
+  if (dtype != MGP_F32 && dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad dtype %d", dtype);
+  if (rows < 0 || cols < 0) return mgp_fail(h, MGP_E_SHAPE, "negative size");
+  if (cols == 0) return MGP_OK;
+  if (!out || (rows > 0 && (!A || !B))) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  dim3 grid((unsigned)((cols + 63) / 64));
+  if (dtype == MGP_F64)
+    hipLaunchKernelGGL((colwise_dot_kernel<double>), grid, dim3(256), 0, h->stream, (const double*)A,
+                       (const double*)B, rows, cols, (double*)out);
+  else
+    hipLaunchKernelGGL((colwise_dot_kernel<float>), grid, dim3(256), 0, h->stream, (const float*)A,
+                       (const float*)B, rows, cols, (float*)out);
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+extern "C" int mgp_dot_all(mgp_handle* h, int dtype, const void* A, const void* B, int64_t count, double* out) {
+  if (!h) return MGP_E_BADARG;
+  if (dtype != MGP_F32 && dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad dtype %d", dtype);
+  if (!out) return mgp_fail(h, MGP_E_BADARG, "out is NULL");
+  *out = 0.0;
+  if (count <= 0) return count == 0 ? MGP_OK : mgp_fail(h, MGP_E_SHAPE, "negative count");
+  if (!A || !B) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  const int nb = 512;
+  MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, nb * sizeof(double)));
+  double* part = (double*)h->ws;
+  if (dtype == MGP_F64)
+    hipLaunchKernelGGL((dot_partial_kernel<double>), dim3(nb), dim3(256), 0, h->stream, (const double*)A,
+                       (const double*)B, count, part);
+  else
+    hipLaunchKernelGGL((dot_partial_kernel<float>), dim3(nb), dim3(256), 0, h->stream, (const float*)A,
+                       (const float*)B, count, part);
+  MGP_LAUNCH_CHECK(h);
+  double host[512];
+  MGP_HIP(h, hipMemcpyAsync(host, part, nb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  MGP_HIP(h, hipStreamSynchronize(h->stream));
+  double s = 0;
+  for (int i = 0; i < nb; ++i) s += host[i];
+  *out = s;
+  return MGP_OK;
+}

@@ -1,0 +1,401 @@
+// cg.hip -- device-resident batched preconditioned conjugate gradient (rows CG1, CG3-CG5).
+//
+// Restates the recurrence of cggp/conjugate_gradient.py:59-98 with every scalar
+// (gamma, beta, rz, the stopping test) kept on the device:
+//
+//   while any_b(0.5 ||r_b||^2 > thr) and i < max_it:                  (:59-62)
+//       Ap = p @ A                                                     (:65)   operator kernel(s)
+//       gamma = rz / (p . Ap), 0 where p.Ap <= min_float               (:66-68)  \
+//       v += gamma p ; r -= gamma Ap   (or r = b - v @ A on a refresh) (:69-76)   | cg_update_kernel
+//       z, rz' = M^-1 r ; p = z + p rz'/rz (0 where rz <= min_float)   (:77-84)  /  one block per RHS
+//
+// The host never sees a scalar: a device word `active` gates every kernel of an iteration, so
+// `check_every` iterations can be enqueued back to back and the ones after convergence are
+// no-ops -- the step count stays exactly the reference's.  The host polls `active` once per
+// batch.  Vectors are [Bt, n] row-major (the function-level layout, :24-32); one workgroup owns
+// one right-hand side, dot products are wavefront shuffles + one LDS hop.
+#include <chrono>
+
+#include "mgp_common.h"
+
+namespace {
+
+struct CgCtrl {
+  int active;
+  int iters;
+};
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // red reuse
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  T s = 0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) s += red[w];  // fixed order: deterministic
+  return s;
+}
+
+struct PrecondDev {
+  int kind;
+  int bs;
+  long nb;
+  const void* diag_inv;
+  const long* block_index;
+  const void* block_inv;
+};
+
+// z = M^-1 r for one RHS row (all threads of the block cooperate); returns nothing, z in memory
+template <typename T>
+__device__ void apply_precond(const PrecondDev& pc, const T* __restrict__ r, T* __restrict__ z, long n) {
+  if (pc.kind == MGP_PRE_JACOBI) {
+    const T* dinv = (const T*)pc.diag_inv;
+    for (long j = threadIdx.x; j < n; j += blockDim.x) z[j] = r[j] * dinv[j];
+  } else {  // MGP_PRE_BLOCK: uncovered indices pass through, covered ones get Binv_k r[idx_k]
+    for (long j = threadIdx.x; j < n; j += blockDim.x) z[j] = r[j];
+    __syncthreads();
+    const T* binv = (const T*)pc.block_inv;
+    const long tot = pc.nb * pc.bs;
+    for (long e = threadIdx.x; e < tot; e += blockDim.x) {
+      const long k = e / pc.bs, a = e - k * pc.bs;
+      const long* idx = pc.block_index + k * pc.bs;
+      const T* row = binv + (k * pc.bs + a) * pc.bs;
+      T s = 0;
+      for (int c = 0; c < pc.bs; ++c) s = mgp_fma(row[c], r[idx[c]], s);
+      z[idx[a]] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// r = b - av (av may be null => r = b); z, rz, p, stopping flag.  Also used for the refresh step.
+template <typename T>
+__global__ __launch_bounds__(256) void cg_init_kernel(const T* __restrict__ b, const T* __restrict__ av,
+                                                      T* __restrict__ r, T* __restrict__ z, T* __restrict__ p,
+                                                      T* __restrict__ rz, int* __restrict__ over,
+                                                      T* __restrict__ err, long n, T thr, PrecondDev pc) {
+  __shared__ T red[8];
+  const long off = (long)blockIdx.x * n;
+  for (long j = threadIdx.x; j < n; j += blockDim.x) r[off + j] = av ? b[off + j] - av[off + j] : b[off + j];
+  __syncthreads();
+  const T* zz = r + off;
+  if (pc.kind != MGP_PRE_EYE) {
+    apply_precond<T>(pc, r + off, z + off, n);
+    zz = z + off;
+  }
+  T s_rz = 0, s_rr = 0;
+  for (long j = threadIdx.x; j < n; j += blockDim.x) {
+    const T rv = r[off + j], zv = zz[j];
+    p[off + j] = zv;
+    s_rz = mgp_fma(zv, rv, s_rz);
+    s_rr = mgp_fma(rv, rv, s_rr);
+  }
+  s_rz = block_sum(s_rz, red);
+  s_rr = block_sum(s_rr, red);
+  if (threadIdx.x == 0) {
+    rz[blockIdx.x] = s_rz;
+    err[blockIdx.x] = (T)0.5 * s_rz;
+    over[blockIdx.x] = ((T)0.5 * s_rr > thr) ? 1 : 0;
+  }
+}
+
+// mode 0: full step.  mode 1: first half only (gamma, v, no r update: refresh follows).
+// mode 2: second half after a refresh (r already = b - v@A): z, rz, p = z, flags.
+template <typename T>
+__global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
+                                                        T* __restrict__ r, T* __restrict__ p,
+                                                        T* __restrict__ z, const T* __restrict__ ap,
+                                                        T* __restrict__ rz, int* __restrict__ over,
+                                                        T* __restrict__ err, long n, T thr, T min_float,
+                                                        PrecondDev pc, int mode) {
+  if (ctrl->active == 0) return;
+  __shared__ T red[8];
+  const long off = (long)blockIdx.x * n;
+  const T rz_old = rz[blockIdx.x];
+  if (mode != 2) {
+    T d = 0;
+    for (long j = threadIdx.x; j < n; j += blockDim.x) d = mgp_fma(p[off + j], ap[off + j], d);
+    d = block_sum(d, red);
+    const T gamma = (d <= min_float) ? (T)0 : rz_old / d;
+    for (long j = threadIdx.x; j < n; j += blockDim.x) {
+      v[off + j] = mgp_fma(gamma, p[off + j], v[off + j]);
+      if (mode == 0) r[off + j] = mgp_fma(-gamma, ap[off + j], r[off + j]);
+    }
+    if (mode == 1) return;
+    __syncthreads();
+  }
+  const T* zz = r + off;
+  if (pc.kind != MGP_PRE_EYE) {
+    apply_precond<T>(pc, r + off, z + off, n);
+    zz = z + off;
+  }
+  T s_rz = 0, s_rr = 0;
+  for (long j = threadIdx.x; j < n; j += blockDim.x) {
+    const T rv = r[off + j], zv = zz[j];
+    s_rz = mgp_fma(zv, rv, s_rz);
+    s_rr = mgp_fma(rv, rv, s_rr);
+  }
+  s_rz = block_sum(s_rz, red);
+  s_rr = block_sum(s_rr, red);
+  const T beta = (mode == 2 || rz_old <= min_float) ? (T)0 : s_rz / rz_old;
+  for (long j = threadIdx.x; j < n; j += blockDim.x) p[off + j] = mgp_fma(beta, p[off + j], zz[j]);
+  if (threadIdx.x == 0) {
+    rz[blockIdx.x] = s_rz;
+    err[blockIdx.x] = (T)0.5 * s_rz;
+    over[blockIdx.x] = ((T)0.5 * s_rr > thr) ? 1 : 0;
+  }
+}
+
+// r = b - av, gated (refresh step, conjugate_gradient.py:72-75)
+template <typename T>
+__global__ __launch_bounds__(256) void cg_residual_kernel(const CgCtrl* __restrict__ ctrl,
+                                                          const T* __restrict__ b, const T* __restrict__ av,
+                                                          T* __restrict__ r, long total) {
+  if (ctrl->active == 0) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) r[i] = b[i] - av[i];
+}
+
+__global__ void cg_advance_kernel(CgCtrl* ctrl, const int* __restrict__ over, long Bt, int inc, int max_it) {
+  __shared__ int any;
+  if (inc && ctrl->active == 0) return;  // uniform: every thread reads the same word
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  int a = 0;
+  for (long b = threadIdx.x; b < Bt; b += blockDim.x) a |= over[b];
+  if (a) atomicOr(&any, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int it = ctrl->iters + inc;
+    ctrl->iters = it;
+    ctrl->active = (any && it < max_it) ? 1 : 0;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const int* __restrict__ gate, T a, const T* __restrict__ x, T b,
+                                                    const T* __restrict__ y, T* __restrict__ out, long total) {
+  if (gate != nullptr && *gate == 0) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = a * x[i] + b * y[i];
+}
+
+// out[b, j] += lam[j] * p[b, j]
+template <typename T>
+__global__ __launch_bounds__(256) void add_diag_prod_kernel(const int* __restrict__ gate, const T* __restrict__ lam,
+                                                            const T* __restrict__ p, T* __restrict__ out, long n,
+                                                            long total) {
+  if (gate != nullptr && *gate == 0) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = mgp_fma(lam[i % n], p[i], out[i]);
+}
+
+inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
+// out[Bt, n] = P[Bt, n] @ Op ; gate may be null
+template <typename T>
+int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T* out, const int* gate) {
+  const long n = op->n;
+  switch (op->kind) {
+    case MGP_OP_DENSE:
+      return mgp_symm_matmul_gated(h, op->dtype, op->A, n, P, Bt, out, gate);
+    case MGP_OP_KMM_LAMBDA: {
+      MGP_TRY(mgp_sweep(h, op->kernel, op->Z, op->M, op->Z, op->M, VecView{P, 1, n}, (int)Bt,
+                        VecViewMut{out, 1, n}, 0.0, VecView{nullptr, 0, 0}, gate));
+      hipLaunchKernelGGL((add_diag_prod_kernel<T>), dim3(nblk(Bt * n)), dim3(256), 0, h->stream, gate,
+                         (const T*)op->lambda, P, out, n, Bt * n);
+      MGP_LAUNCH_CHECK(h);
+      return MGP_OK;
+    }
+    case MGP_OP_SGPR: {
+      // u[Bt, N] = (K_nm p^T)^T ; t[Bt, M] = (K_mn u^T)^T ; all-reduce t ; out = s2 * p @ Kmm + t
+      const long N = op->N, M = op->M;
+      const size_t need = ((size_t)Bt * N + (size_t)Bt * M) * sizeof(T);
+      MGP_TRY(mgp_reserve(h, &h->opws, &h->opws_bytes, need));
+      T* u = (T*)h->opws;
+      T* tt = op->partial_buf ? (T*)op->partial_buf : u + Bt * N;
+      if (N > 0) {
+        MGP_TRY(mgp_sweep(h, op->kernel, op->X, N, op->Z, M, VecView{P, 1, M}, (int)Bt, VecViewMut{u, 1, N}, 0.0,
+                          VecView{nullptr, 0, 0}, gate));
+        MGP_TRY(mgp_sweep(h, op->kernel, op->Z, M, op->X, N, VecView{u, 1, N}, (int)Bt, VecViewMut{tt, 1, M}, 0.0,
+                          VecView{nullptr, 0, 0}, gate));
+      } else {
+        MGP_HIP(h, hipMemsetAsync(tt, 0, (size_t)Bt * M * sizeof(T), h->stream));
+      }
+      MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, op->Kmm, M, P, Bt, out, gate));
+      if (op->allreduce) {
+        const int rc = op->allreduce(op->allreduce_ctx, tt, (size_t)(Bt * M), op->dtype, (void*)h->stream);
+        if (rc != 0) return mgp_fail(h, MGP_E_COMM, "allreduce callback returned %d", rc);
+      }
+      hipLaunchKernelGGL((axpby_kernel<T>), dim3(nblk(Bt * M)), dim3(256), 0, h->stream, gate, (T)op->s2,
+                         (const T*)out, (T)1, (const T*)tt, out, Bt * M);
+      MGP_LAUNCH_CHECK(h);
+      return MGP_OK;
+    }
+    default:
+      return mgp_fail(h, MGP_E_BADARG, "unknown operator kind %d", op->kind);
+  }
+}
+
+int check_operator(mgp_handle* h, const mgp_operator* op) {
+  if (!op) return mgp_fail(h, MGP_E_BADARG, "operator is NULL");
+  if (op->dtype != MGP_F32 && op->dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad operator dtype");
+  if (op->n <= 0) return mgp_fail(h, MGP_E_SHAPE, "operator n must be > 0");
+  if (op->kind == MGP_OP_DENSE) {
+    if (!op->A) return mgp_fail(h, MGP_E_BADARG, "dense operator without matrix");
+  } else if (op->kind == MGP_OP_SGPR || op->kind == MGP_OP_KMM_LAMBDA) {
+    MGP_TRY(mgp_check_kernel(h, op->kernel));
+    if (op->kernel->dtype != op->dtype) return mgp_fail(h, MGP_E_DTYPE, "operator/kernel dtype mismatch");
+    if (op->M != op->n || !op->Z) return mgp_fail(h, MGP_E_SHAPE, "operator needs Z with M == n");
+    if (op->kind == MGP_OP_SGPR && (!op->Kmm || op->N < 0 || (op->N > 0 && !op->X)))
+      return mgp_fail(h, MGP_E_BADARG, "SGPR operator needs X and Kmm");
+    if (op->kind == MGP_OP_KMM_LAMBDA && !op->lambda) return mgp_fail(h, MGP_E_BADARG, "needs lambda");
+  } else {
+    return mgp_fail(h, MGP_E_BADARG, "unknown operator kind %d", op->kind);
+  }
+  return MGP_OK;
+}
+
+template <typename T>
+int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, const T* B, const T* V0, long Bt,
+                double thr, long max_it, long cycle, double min_float, int check_every, T* V, T* err_out,
+                mgp_cg_stats* stats) {
+  const long n = op->n;
+  const long tot = Bt * n;
+  const auto t0 = std::chrono::steady_clock::now();
+  PrecondDev pc{MGP_PRE_EYE, 0, 0, nullptr, nullptr, nullptr};
+  if (pre) {
+    pc.kind = pre->kind;
+    if (pre->kind == MGP_PRE_JACOBI) {
+      if (!pre->diag_inv) return mgp_fail(h, MGP_E_BADARG, "jacobi preconditioner without diag_inv");
+      pc.diag_inv = pre->diag_inv;
+    } else if (pre->kind == MGP_PRE_BLOCK) {
+      if (!pre->block_index || !pre->block_inv || pre->block_size <= 0 || pre->num_blocks < 0)
+        return mgp_fail(h, MGP_E_BADARG, "block preconditioner incomplete");
+      pc.bs = pre->block_size;
+      pc.nb = pre->num_blocks;
+      pc.block_index = (const long*)pre->block_index;
+      pc.block_inv = pre->block_inv;
+    } else if (pre->kind != MGP_PRE_EYE) {
+      return mgp_fail(h, MGP_E_BADARG, "unknown preconditioner kind %d", pre->kind);
+    }
+  }
+  const bool need_z = pc.kind != MGP_PRE_EYE;
+  // arena: r, p, ap, [z], rz[Bt], over[Bt] (int), ctrl
+  size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64;
+  MGP_TRY(mgp_reserve(h, &h->cg, &h->cg_bytes, bytes));
+  T* r = (T*)h->cg;
+  T* p = r + tot;
+  T* ap = p + tot;
+  T* z = need_z ? ap + tot : nullptr;
+  T* rz = (need_z ? z : ap) + tot;
+  int* over = (int*)(rz + Bt);
+  CgCtrl* ctrl = (CgCtrl*)(((uintptr_t)(over + Bt) + 15) & ~(uintptr_t)15);
+  hipStream_t s = h->stream;
+
+  MGP_HIP(h, hipMemsetAsync(ctrl, 0, sizeof(CgCtrl), s));
+  const T* av = nullptr;
+  if (V0) {
+    if (V != V0) MGP_HIP(h, hipMemcpyAsync(V, V0, (size_t)tot * sizeof(T), hipMemcpyDeviceToDevice, s));
+    MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, nullptr));  // vA (:87)
+    av = ap;
+  } else {
+    MGP_HIP(h, hipMemsetAsync(V, 0, (size_t)tot * sizeof(T), s));
+  }
+  hipLaunchKernelGGL((cg_init_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, B, av, r, z, p, rz, over, err_out, n,
+                     (T)thr, pc);
+  MGP_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 0, (int)max_it);
+  MGP_LAUNCH_CHECK(h);
+
+  if (check_every < 1) check_every = 1;
+  long enq = 0;  // iterations enqueued so far (index of the next one)
+  CgCtrl host{1, 0};
+  while (true) {
+    MGP_HIP(h, hipMemcpyAsync(h->host_flag, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, s));
+    MGP_HIP(h, hipStreamSynchronize(s));
+    memcpy(&host, h->host_flag, sizeof(CgCtrl));
+    if (!host.active || enq >= max_it) break;
+    long batch = check_every;
+    if (enq + batch > max_it) batch = max_it - enq;
+    for (long q = 0; q < batch; ++q, ++enq) {
+      const bool reset = (enq % cycle) == (cycle - 1);  // :71 (enq == state.i while active)
+      MGP_TRY(apply_operator<T>(h, op, p, Bt, ap, &ctrl->active));
+      if (!reset) {
+        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                           over, err_out, n, (T)thr, (T)min_float, pc, 0);
+      } else {
+        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                           over, err_out, n, (T)thr, (T)min_float, pc, 1);
+        MGP_LAUNCH_CHECK(h);
+        MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, &ctrl->active));
+        hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot);
+        MGP_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                           over, err_out, n, (T)thr, (T)min_float, pc, 2);
+      }
+      MGP_LAUNCH_CHECK(h);
+      hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 1, (int)max_it);
+      MGP_LAUNCH_CHECK(h);
+    }
+  }
+  if (stats) {
+    stats->iterations = host.iters;
+    // converged iff the loop ended because no RHS was over threshold
+    int any = 0;
+    {
+      // `active` == 0 with iters < max_it means converged; at the cap, look at the flags
+      if (host.iters < max_it) {
+        any = 0;
+      } else {
+        std::string tmp;
+        tmp.resize((size_t)Bt * sizeof(int));
+        MGP_HIP(h, hipMemcpyAsync(&tmp[0], over, (size_t)Bt * sizeof(int), hipMemcpyDeviceToHost, s));
+        MGP_HIP(h, hipStreamSynchronize(s));
+        const int* f = (const int*)tmp.data();
+        for (long b = 0; b < Bt; ++b) any |= f[b];
+      }
+    }
+    stats->converged = any ? 0 : 1;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return MGP_OK;
+}
+
+}  // namespace
+
+extern "C" int mgp_pcg_solve(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, const void* B,
+                             const void* V0, int64_t Bt, double error_threshold, int64_t max_iterations,
+                             int64_t max_steps_cycle, double min_float, int32_t check_every, void* V_out,
+                             void* err_out, mgp_cg_stats* stats) {
+  if (!h) return MGP_E_BADARG;
+  MGP_TRY(check_operator(h, op));
+  if (Bt < 0) return mgp_fail(h, MGP_E_SHAPE, "Bt < 0");
+  if (stats) {
+    stats->iterations = 0;
+    stats->converged = 1;
+    stats->seconds = 0.0;
+  }
+  if (Bt == 0) return MGP_OK;
+  if (!B || !V_out || !err_out) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (max_iterations < 0) return mgp_fail(h, MGP_E_BADARG, "max_iterations < 0");
+  if (max_steps_cycle < 1) return mgp_fail(h, MGP_E_BADARG, "max_steps_cycle < 1");
+  if (Bt > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "Bt too large");
+  if (op->dtype == MGP_F64)
+    return pcg_solve_t<double>(h, op, pre, (const double*)B, (const double*)V0, Bt, error_threshold, max_iterations,
+                               max_steps_cycle, min_float, check_every, (double*)V_out, (double*)err_out, stats);
+  return pcg_solve_t<float>(h, op, pre, (const float*)B, (const float*)V0, Bt, error_threshold, max_iterations,
+                            max_steps_cycle, min_float, check_every, (float*)V_out, (float*)err_out, stats);
+}
+
+extern "C" int mgp_operator_apply(mgp_handle* h, const mgp_operator* op, const void* P, int64_t Bt, void* out) {
+  if (!h) return MGP_E_BADARG;
+  MGP_TRY(check_operator(h, op));
+  if (Bt <= 0) return Bt == 0 ? MGP_OK : mgp_fail(h, MGP_E_SHAPE, "Bt < 0");
+  if (!P || !out) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (op->dtype == MGP_F64) return apply_operator<double>(h, op, (const double*)P, Bt, (double*)out, nullptr);
+  return apply_operator<float>(h, op, (const float*)P, Bt, (float*)out, nullptr);
+}

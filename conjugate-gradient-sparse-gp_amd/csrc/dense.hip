@@ -1,0 +1,312 @@
+// dense.hip -- explicit kernel blocks and the dense symmetric product of the CG step.
+//
+//   mgp_k_dense      out[na, nb] = k(A, B) (+ jitter, + diag_add)       rows K3, K4
+//   mgp_symm_matmul  out[Bt, n] = P[Bt, n] @ A[n, n], A symmetric       row M2 (`p @ A`)
+//
+// The product has two regimes: Bt <= 8 is a GEMV family (HBM-bound: A is read once,
+// s(n^2 + 2 n Bt) bytes) done with coalesced 16-byte row reads and wavefront reductions;
+// larger Bt is a GEMM on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 128x128 tiles
+// staged through LDS.  fp32 uses v_mfma_f32_16x16x4_f32 with the same tiling.
+#include "mgp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ k_dense
+template <typename T, int DP, int KIND>
+__global__ __launch_bounds__(256) void k_dense_kernel(const T* __restrict__ A, long na,
+                                                      const T* __restrict__ B, long nb, T* __restrict__ out,
+                                                      long ld, int D, SweepParams prm, T jitter,
+                                                      const T* __restrict__ diag_add) {
+  constexpr int TA = 16;  // rows of A per block
+  constexpr int PS = (DP + 1 + 1) & ~1;
+  __shared__ __attribute__((aligned(16))) T tile[TA * PS];
+  const int t = threadIdx.x;
+  const long j = (long)blockIdx.x * 256 + t;
+  const long i0 = (long)blockIdx.y * TA;
+  if (t < TA) {
+    const long i = i0 + t;
+    T* p = &tile[t * PS];
+    T s = 0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      T v = (d < D && i < na) ? A[i * D + d] * (T)prm.inv_ls[d] : (T)0;
+      s = mgp_fma(v, v, s);
+      p[d] = v + v;
+    }
+    p[DP] = -s;
+  }
+  T b[DP];
+  T b2 = 0;
+  {
+    const long jc = j < nb ? j : nb - 1;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      T v = d < D ? B[jc * D + d] * (T)prm.inv_ls[d] : (T)0;
+      b[d] = v;
+      b2 = mgp_fma(v, v, b2);
+    }
+  }
+  __syncthreads();
+  if (j >= nb) return;
+  const T var = (T)prm.variance;
+  const T clamp = (T)prm.clamp;
+#pragma unroll 4
+  for (int ii = 0; ii < TA; ++ii) {
+    const long i = i0 + ii;
+    if (i >= na) break;
+    const T* p = &tile[ii * PS];
+    T s = p[DP] - b2;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) s = mgp_fma(b[d], p[d], s);
+    T v = var * mgp_profile<KIND, T>(s, clamp);
+    if (i == j) {
+      v += jitter;
+      if (diag_add != nullptr) v += diag_add[i];
+    }
+    out[i * ld + j] = v;
+  }
+}
+
+template <typename T, int KIND>
+int k_dense_dp(mgp_handle* h, const SweepParams& prm, int D, const T* A, long na, const T* B, long nb, T* out,
+               long ld, T jitter, const T* diag_add) {
+  dim3 grid((unsigned)((nb + 255) / 256), (unsigned)((na + 15) / 16));
+#define MGP_KD(DPV)                                                                                         \
+  hipLaunchKernelGGL((k_dense_kernel<T, DPV, KIND>), grid, dim3(256), 0, h->stream, A, na, B, nb, out, ld, D, \
+                     prm, jitter, diag_add)
+  if (D <= 2) MGP_KD(2);
+  else if (D <= 4) MGP_KD(4);
+  else if (D <= 8) MGP_KD(8);
+  else if (D <= 16) MGP_KD(16);
+  else MGP_KD(32);
+#undef MGP_KD
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+template <typename T>
+int k_dense_t(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* B, long nb, T* out, long ld,
+              double jitter, const T* diag_add) {
+  const SweepParams prm = mgp_make_params(k);
+  switch (k->kind) {
+    case MGP_SE: return k_dense_dp<T, 0>(h, prm, k->D, A, na, B, nb, out, ld, (T)jitter, diag_add);
+    case MGP_MATERN12: return k_dense_dp<T, 1>(h, prm, k->D, A, na, B, nb, out, ld, (T)jitter, diag_add);
+    case MGP_MATERN32: return k_dense_dp<T, 2>(h, prm, k->D, A, na, B, nb, out, ld, (T)jitter, diag_add);
+    default: return k_dense_dp<T, 3>(h, prm, k->D, A, na, B, nb, out, ld, (T)jitter, diag_add);
+  }
+}
+
+// ------------------------------------------------------------------ GEMV family (Bt <= 8)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// one wave per RW rows of A; lanes stride the row in VEC-element pieces
+template <typename T, int BT, int VEC>
+__global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A, long n,
+                                                        const T* __restrict__ P, int bt, T* __restrict__ out,
+                                                        const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int RW = 2;
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= n) return;
+  T acc[RW][BT];
+#pragma unroll
+  for (int q = 0; q < RW; ++q)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[q][b] = 0;
+  const long r1 = row0 + 1 < n ? row0 + 1 : row0;
+  const T* a0 = A + row0 * n;
+  const T* a1 = A + r1 * n;
+  for (long i = (long)lane * VEC; i < n; i += 64 * VEC) {
+    T x0[VEC], x1[VEC];
+    if (VEC == 1) {
+      x0[0] = a0[i];
+      x1[0] = a1[i];
+    } else {
+      // VEC*sizeof(T) == 16 bytes, rows are 16-B aligned because n % VEC == 0
+      using V = __attribute__((ext_vector_type(VEC))) T;
+      const V v0 = *reinterpret_cast<const V*>(a0 + i);
+      const V v1 = *reinterpret_cast<const V*>(a1 + i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        x0[e] = v0[e];
+        x1[e] = v1[e];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b < bt) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const T pv = P[(long)b * n + i + e];
+          acc[0][b] = mgp_fma(x0[e], pv, acc[0][b]);
+          acc[1][b] = mgp_fma(x1[e], pv, acc[1][b]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RW; ++q)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const T s = wave_sum(acc[q][b]);
+      if (lane == 0 && b < bt && row0 + q < n) out[(long)b * n + row0 + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------ MFMA GEMM (Bt > 8)
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+  using Acc = __attribute__((ext_vector_type(4))) double;
+  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Mfma<float> {
+  using Acc = __attribute__((ext_vector_type(4))) float;
+  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+// C[Bt, n] = P[Bt, n] . A[n, n]^T  (A symmetric => P @ A).  Block tile 128(b) x 128(j), BK = 16,
+// 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles.  Both operand tiles are [row][k] row-major,
+// so global reads are 16-byte pieces along k and LDS reads are the same pattern for both.
+template <typename T>
+__global__ __launch_bounds__(256) void symm_gemm_kernel(const T* __restrict__ A, long n,
+                                                        const T* __restrict__ P, long Bt, T* __restrict__ out,
+                                                        const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int BM = 128, BN = 128, BK = 16, LDS_S = BK + 2;  // stride 18: conflict-free b64 reads
+  __shared__ __attribute__((aligned(16))) T Ps[BM * LDS_S];
+  __shared__ __attribute__((aligned(16))) T As[BN * LDS_S];
+  using Acc = typename Mfma<T>::Acc;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long b0 = (long)blockIdx.y * BM, j0 = (long)blockIdx.x * BN;
+
+  Acc acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[m][q] = Acc{0, 0, 0, 0};
+
+  // staging: tile has 128 rows x 16 k = 2048 elements; thread loads 8 consecutive k of one row
+  const int srow = t >> 1, skk = (t & 1) * 8;
+  T pre_p[8], pre_a[8];
+  auto load_tiles = [&](long k0) {
+    const long pb = b0 + srow, aj = j0 + srow;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long k = k0 + skk + e;
+      pre_p[e] = (pb < Bt && k < n) ? P[pb * n + k] : (T)0;
+      pre_a[e] = (aj < n && k < n) ? A[aj * n + k] : (T)0;
+    }
+  };
+  load_tiles(0);
+  for (long k0 = 0; k0 < n; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Ps[srow * LDS_S + skk + e] = pre_p[e];
+      As[srow * LDS_S + skk + e] = pre_a[e];
+    }
+    __syncthreads();
+    if (k0 + BK < n) load_tiles(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T af[4], bf[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = Ps[(wm * 64 + m * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[q] = As[(wn * 64 + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q] = Mfma<T>::run(af[m], bf[q], acc[m][q]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long b = b0 + wm * 64 + m * 16 + Mfma<T>::row(lane, r);
+        const long j = j0 + wn * 64 + q * 16 + (lane & 15);
+        if (b < Bt && j < n) out[b * n + j] = acc[m][q][r];
+      }
+}
+
+template <typename T>
+int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out, const int* gate) {
+  if (Bt > 8) {
+    dim3 grid((unsigned)((n + 127) / 128), (unsigned)((Bt + 127) / 128));
+    hipLaunchKernelGGL((symm_gemm_kernel<T>), grid, dim3(256), 0, h->stream, A, n, P, Bt, out, gate);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
+  }
+  constexpr int VECW = 16 / sizeof(T);
+  const bool vec = (n % VECW) == 0 && (((uintptr_t)A) % 16) == 0;
+  dim3 grid((unsigned)((n + 7) / 8));
+#define MGP_GV(BTV)                                                                                             \
+  do {                                                                                                          \
+    if (vec)                                                                                                    \
+      hipLaunchKernelGGL((symm_gemv_kernel<T, BTV, VECW>), grid, dim3(256), 0, h->stream, A, n, P, (int)Bt, out, \
+                         gate);                                                                                 \
+    else                                                                                                        \
+      hipLaunchKernelGGL((symm_gemv_kernel<T, BTV, 1>), grid, dim3(256), 0, h->stream, A, n, P, (int)Bt, out,    \
+                         gate);                                                                                 \
+  } while (0)
+  if (Bt == 1) MGP_GV(1);
+  else if (Bt == 2) MGP_GV(2);
+  else if (Bt <= 4) MGP_GV(4);
+  else MGP_GV(8);
+#undef MGP_GV
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+}  // namespace
+
+int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
+                          void* out, const int* gate) {
+  if (!h) return MGP_E_BADARG;
+  if (dtype != MGP_F32 && dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad dtype %d", dtype);
+  if (n < 0 || Bt < 0) return mgp_fail(h, MGP_E_SHAPE, "negative size");
+  if (n == 0 || Bt == 0) return MGP_OK;
+  if (!A || !P || !out) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (dtype == MGP_F64) return symm_matmul_t<double>(h, (const double*)A, n, (const double*)P, Bt, (double*)out, gate);
+  return symm_matmul_t<float>(h, (const float*)A, n, (const float*)P, Bt, (float*)out, gate);
+}
+
+extern "C" int mgp_symm_matmul(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
+                               void* out) {
+  return mgp_symm_matmul_gated(h, dtype, A, n, P, Bt, out, nullptr);
+}
+
+extern "C" int mgp_k_dense(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B,
+                           int64_t nb, void* out, int64_t ld, double jitter, const void* diag_add) {
+  MGP_TRY(mgp_check_kernel(h, k));
+  if (na < 0 || nb < 0 || ld < nb) return mgp_fail(h, MGP_E_SHAPE, "k_dense: bad shape na=%ld nb=%ld ld=%ld",
+                                                   (long)na, (long)nb, (long)ld);
+  if (na == 0 || nb == 0) return MGP_OK;
+  if (!A || !B || !out) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (k->dtype == MGP_F64)
+    return k_dense_t<double>(h, k, (const double*)A, na, (const double*)B, nb, (double*)out, ld, jitter,
+                             (const double*)diag_add);
+  return k_dense_t<float>(h, k, (const float*)A, na, (const float*)B, nb, (float*)out, ld, jitter,
+                          (const float*)diag_add);
+}

@@ -1,0 +1,124 @@
+// mgp_common.h -- handle, workspace arena, error plumbing shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/mgp.h"
+#include "mgp_math.h"
+
+struct mgp_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  // device workspace (partials of the two-stage reductions, CG state); grown on demand
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // CG state arena, separate from ws so operator applications inside the solve can use ws
+  void* cg = nullptr;
+  size_t cg_bytes = 0;
+  // operator scratch (u = K_nm p and the [Bt,M] partial of the SGPR operator)
+  void* opws = nullptr;
+  size_t opws_bytes = 0;
+  // pinned host word for the convergence poll
+  int* host_flag = nullptr;
+  int num_cus = 256;
+};
+
+inline int mgp_fail(mgp_handle* h, int code, const char* fmt, ...) {
+  if (h) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(h->err, sizeof(h->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define MGP_HIP(h, call)                                                                  \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return mgp_fail((h), MGP_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define MGP_TRY(call)          \
+  do {                         \
+    int rc__ = (call);         \
+    if (rc__ != MGP_OK) return rc__; \
+  } while (0)
+
+#define MGP_LAUNCH_CHECK(h) MGP_HIP((h), hipGetLastError())
+
+// grow-only arenas; never called during stream capture (callers size up front)
+inline int mgp_reserve(mgp_handle* h, void** p, size_t* have, size_t need) {
+  if (need <= *have) return MGP_OK;
+  if (*p) {
+    MGP_HIP(h, hipStreamSynchronize(h->stream));
+    MGP_HIP(h, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  size_t want = need + (need >> 2) + 4096;
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) return mgp_fail(h, MGP_E_NOMEM, "workspace hipMalloc(%zu) failed: %s", want,
+                                        hipGetErrorString(e));
+  *have = want;
+  return MGP_OK;
+}
+
+inline size_t mgp_elem(int dtype) { return dtype == MGP_F64 ? 8 : 4; }
+
+inline int mgp_check_kernel(mgp_handle* h, const mgp_kernel* k) {
+  if (!h) return MGP_E_BADARG;
+  if (!k) return mgp_fail(h, MGP_E_BADARG, "kernel is NULL");
+  if (k->kind < MGP_SE || k->kind > MGP_MATERN52) return mgp_fail(h, MGP_E_BADARG, "bad kernel kind %d", k->kind);
+  if (k->dtype != MGP_F32 && k->dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad dtype %d", k->dtype);
+  if (k->D < 1 || k->D > MGP_MAX_D) return mgp_fail(h, MGP_E_SHAPE, "D=%d outside [1,%d]", k->D, MGP_MAX_D);
+  if (!(k->variance > 0.0)) return mgp_fail(h, MGP_E_BADARG, "variance must be > 0");
+  for (int d = 0; d < k->D; ++d)
+    if (!(k->lengthscales[d] > 0.0)) return mgp_fail(h, MGP_E_BADARG, "lengthscale[%d] must be > 0", d);
+  return MGP_OK;
+}
+
+// Scaled kernel parameters passed by value to device code.
+struct SweepParams {
+  double inv_ls[MGP_MAX_D];  // c_kind / lengthscale_d
+  double variance;
+  double clamp;  // c_kind^2 * 1e-36
+};
+
+inline SweepParams mgp_make_params(const mgp_kernel* k) {
+  SweepParams p;
+  const double c = mgp_profile_scale(k->kind);
+  for (int d = 0; d < MGP_MAX_D; ++d) p.inv_ls[d] = d < k->D ? c / k->lengthscales[d] : 0.0;
+  p.variance = k->variance;
+  p.clamp = c * c * 1e-36;
+  return p;
+}
+
+// internal cross-TU entry points (layout-generic forms of the public calls)
+struct VecView {  // element (i, r) of a batch of vectors lives at base[i*si + r*sr]
+  const void* base;
+  int64_t si, sr;
+};
+struct VecViewMut {
+  void* base;
+  int64_t si, sr;
+};
+inline VecView mgp_view(const void* p, int64_t n, int64_t R, int layout) {
+  return layout == MGP_COLS ? VecView{p, R, 1} : VecView{p, 1, n};
+}
+inline VecViewMut mgp_view_mut(void* p, int64_t n, int64_t R, int layout) {
+  return layout == MGP_COLS ? VecViewMut{p, R, 1} : VecViewMut{p, 1, n};
+}
+
+// out(i,r) = variance * sum_j k(a_i, b_j) w(j,r) [+ alpha * addend(i,r)];  gate: device int, skip if 0
+int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
+              VecView W, int32_t R, VecViewMut out, double alpha, VecView addend, const int* gate);
+int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
+                          void* out, const int* gate);

@@ -1,0 +1,88 @@
+// mgp_math.h -- scalar math shared by every kernel: exp2 on a reduced argument and the
+// stationary-kernel profiles of SURVEY §8a row K2 (GPflow SquaredExponential / Matern12/32/52).
+//
+// The header also compiles with plain g++ (MGP_HD expands to nothing) so that
+// tests/test_host_math.py can check the polynomial against libm on the CPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define MGP_HD __host__ __device__ __forceinline__
+#else
+#define MGP_HD inline
+#endif
+
+#define MGP_LOG2E 1.4426950408889634074
+#define MGP_LN2 0.69314718055994530942
+
+// 2^t for double.  n = rint(t), f = t - n in [-0.5, 0.5] (exact), 2^f = 1 + f*q(f) with q the
+// degree-10 near-minimax fit of (2^f - 1)/f (fit error 1.3e-17, see csrc/gen_exp2_coeffs.py),
+// so 2^0 == 1 exactly and k(x,x) == variance exactly.  13 fp64 VALU instructions + cvt + ldexp.
+MGP_HD double mgp_exp2(double t) {
+  const double n = __builtin_rint(t);
+  const double f = t - n;
+  double q = 0x1.e9d3fe3952179p-32;
+  q = __builtin_fma(q, f, 0x1.e6063f7217bc6p-28);
+  q = __builtin_fma(q, f, 0x1.b524fae627834p-24);
+  q = __builtin_fma(q, f, 0x1.62bfd47773353p-20);
+  q = __builtin_fma(q, f, 0x1.ffcbfc670dcd4p-17);
+  q = __builtin_fma(q, f, 0x1.430913096fd9fp-13);
+  q = __builtin_fma(q, f, 0x1.5d87fe78a5276p-10);
+  q = __builtin_fma(q, f, 0x1.3b2ab6fba1ddap-7);
+  q = __builtin_fma(q, f, 0x1.c6b08d704a0c2p-5);
+  q = __builtin_fma(q, f, 0x1.ebfbdff82c598p-3);
+  q = __builtin_fma(q, f, 0x1.62e42fefa39efp-1);
+  const double p = __builtin_fma(q, f, 1.0);
+  // t is <= ~0 on every call path; clamp keeps the int conversion defined for huge |t|
+  const double nc = n < -2000.0 ? -2000.0 : n;
+  return __builtin_ldexp(p, (int)nc);
+}
+
+MGP_HD float mgp_exp2(float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(t);  // v_exp_f32, 1 ulp
+#else
+  return exp2f(t);
+#endif
+}
+
+MGP_HD double mgp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+MGP_HD float mgp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+MGP_HD double mgp_sqrt(double x) { return __builtin_sqrt(x); }
+MGP_HD float mgp_sqrt(float x) { return __builtin_sqrtf(x); }
+
+// Input scaling c_kind such that, with a = x*c/l and b = z*c/l,
+//   s := |a-b|^2 = c^2 r^2   feeds the profile directly in base 2:
+//   SE        k = var * 2^(-s)                      c^2 = log2(e)/2
+//   Matern12  k = var * 2^(-q),           q = sqrt(s) = r log2e        c = log2e
+//   Matern32  k = var * (1 + q ln2) 2^(-q),        q = sqrt3 r log2e   c = sqrt3 log2e
+//   Matern52  k = var * (1 + q ln2 + q^2 ln2^2/3) 2^(-q), q = sqrt5 r log2e
+// (GPflow: K_r2 / K_r of gpflow/kernels/stationaries.py; r = sqrt(max(r2, 1e-36)).)
+inline double mgp_profile_scale(int kind) {
+  switch (kind) {
+    case 0: return std::sqrt(0.5 * MGP_LOG2E);
+    case 1: return MGP_LOG2E;
+    case 2: return std::sqrt(3.0) * MGP_LOG2E;
+    default: return std::sqrt(5.0) * MGP_LOG2E;
+  }
+}
+
+// neg_s = 2 a.b - |a|^2 - |b|^2 = -s (the expansion form GPflow's square_distance uses).
+// clamp = c^2 * 1e-36 (GPflow's floor under the sqrt, in scaled units).
+template <int KIND, typename T>
+MGP_HD T mgp_profile(T neg_s, T clamp) {
+  if (KIND == 0) {
+    return mgp_exp2(neg_s);
+  } else {
+    T s = -neg_s;
+    s = s > clamp ? s : clamp;
+    const T q = mgp_sqrt(s);
+    const T e = mgp_exp2(-q);
+    if (KIND == 1) return e;
+    if (KIND == 2) return mgp_fma(q, (T)MGP_LN2, (T)1.0) * e;
+    const T c2 = (T)(MGP_LN2 * MGP_LN2 / 3.0);
+    return mgp_fma(mgp_fma(q, c2, (T)MGP_LN2), q, (T)1.0) * e;
+  }
+}

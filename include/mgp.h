@@ -1,0 +1,179 @@
+/*
+ * mgp.h -- C ABI of libmgp (MI355X / gfx950 HIP kernels for the CG + kernel-matvec path).
+ *
+ * Drop-in boundary of SURVEY.md §8(b).  The reference (awav/conjugate-gradient-sparse-gp)
+ * has no FFI of its own: its boundary is the Python call surface of cggp/conjugate_gradient.py,
+ * cggp/models.py and cggp/distance.py.  Each entry point below names the reference
+ * interface (file:line under /root/reference) whose arithmetic it replaces; the Python
+ * host side (conjugate-gradient-sparse-gp_amd/cggp) binds these with ctypes and mirrors the
+ * reference's names and argument meaning on top.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every data pointer is a DEVICE pointer unless a
+ *    parameter says "host"; row-major, contiguous, 16-byte aligned base.
+ *  - the caller owns every buffer it passes.  The library owns only its handle and a
+ *    device workspace that it grows on demand (never while a stream capture is active).
+ *  - every function returns 0 on success or a negative MGP_E_* code and never throws or
+ *    exits; mgp_last_error() gives the message.  CG non-convergence is NOT an error (the
+ *    reference returns the last iterate silently, conjugate_gradient.py:93-98); it is
+ *    reported through mgp_cg_stats.
+ *  - all work is enqueued on the handle's stream (mgp_set_stream); the only host
+ *    synchronisations are the convergence poll of mgp_pcg_solve and explicit stats readback.
+ *  - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef MGP_H
+#define MGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGP_VERSION 100 /* 0.1.0 */
+#define MGP_MAX_D 32    /* input dimensions supported by the fused sweeps */
+
+enum { MGP_OK = 0, MGP_E_BADARG = -1, MGP_E_SHAPE = -2, MGP_E_DTYPE = -3, MGP_E_HIP = -4,
+       MGP_E_COMM = -5, MGP_E_NOMEM = -6 };
+
+enum { MGP_F32 = 0, MGP_F64 = 1 };
+
+/* GPflow stationary kernels reachable in the reference (cggp/cli_utils.py:105-108,455-473;
+ * cg_test.py:14): K2 of SURVEY §8a. */
+enum { MGP_SE = 0, MGP_MATERN12 = 1, MGP_MATERN32 = 2, MGP_MATERN52 = 3 };
+
+/* layout of a batch of vectors: MGP_COLS = [n, R] (the facade layout of
+ * ConjugateGradient.__call__, conjugate_gradient.py:180-212), MGP_ROWS = [R, n] (the
+ * function-level layout of conjugate_gradient(), conjugate_gradient.py:24-32). */
+enum { MGP_COLS = 0, MGP_ROWS = 1 };
+
+enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2 };
+
+enum { MGP_OP_DENSE = 0, MGP_OP_SGPR = 1, MGP_OP_KMM_LAMBDA = 2 };
+
+typedef struct mgp_handle mgp_handle;
+
+/* Kernel hyper-parameters (host memory).  lengthscales has D entries (ARD; repeat the
+ * value for an isotropic kernel).  Replaces gpflow.kernels.* parameter objects. */
+typedef struct {
+  int32_t kind;  /* MGP_SE ... */
+  int32_t dtype; /* MGP_F32 | MGP_F64: element type of every data pointer of the call */
+  int32_t D;
+  int32_t reserved;
+  double variance;
+  double lengthscales[MGP_MAX_D];
+} mgp_kernel;
+
+/* Optional collective hook: sum `count` elements of `buf` (device) in place over all ranks,
+ * enqueued on `stream`.  NULL = single rank.  Used only for the [M,R] partial product of the
+ * row-sharded SGPR operator -- one call per operator application. */
+typedef int (*mgp_allreduce_fn)(void* ctx, void* buf, size_t count, int dtype, void* stream);
+
+/* Linear operator handed to mgp_pcg_solve (the `matrix` argument of
+ * conjugate_gradient(), conjugate_gradient.py:24-27, generalised to matrix-free forms). */
+typedef struct {
+  int32_t kind;  /* MGP_OP_* */
+  int32_t dtype;
+  int64_t n;     /* operator is n x n */
+  /* MGP_OP_DENSE: explicit symmetric matrix A [n,n] */
+  const void* A;
+  /* MGP_OP_SGPR: S = s2 * Kmm_j + K_mn K_nm with K_nm matrix-free over the local row shard.
+   * Kmm_j [M,M] dense = k(Z,Z) + jitter I (replicated).  n = M. */
+  const mgp_kernel* kernel;
+  const void* X; int64_t N;
+  const void* Z; int64_t M;
+  const void* Kmm;
+  double s2;
+  /* MGP_OP_KMM_LAMBDA: (k(Z,Z) + diag(lambda)) applied matrix-free; lambda [M] device */
+  const void* lambda;
+  mgp_allreduce_fn allreduce; void* allreduce_ctx;
+  /* MGP_OP_SGPR, optional: caller-owned [Bt_max, M] device buffer that receives the local partial
+   * K_mn(K_nm p) before the collective (so a host-side collective can address it as its own
+   * tensor); NULL = library scratch. */
+  void* partial_buf;
+} mgp_operator;
+
+typedef struct {
+  int32_t kind;               /* MGP_PRE_* */
+  int32_t block_size;         /* MGP_PRE_BLOCK: bs */
+  int64_t num_blocks;         /* MGP_PRE_BLOCK: nb */
+  const void* diag_inv;       /* MGP_PRE_JACOBI: 1/diag(A) [n] device */
+  const int64_t* block_index; /* MGP_PRE_BLOCK: [nb, bs] int64 device */
+  const void* block_inv;      /* MGP_PRE_BLOCK: inverse of A[idx,idx], [nb, bs, bs] device */
+} mgp_precond;
+
+typedef struct {
+  int32_t iterations; /* CG steps taken == reference stats_steps (conjugate_gradient.py:96) */
+  int32_t converged;  /* 1 iff all_b(0.5*||r_b||^2 <= thr) at exit */
+  double seconds;     /* wall time of the solve (host clock around the enqueue + poll) */
+} mgp_cg_stats;
+
+/* ---- handle ------------------------------------------------------------------------- */
+int mgp_version(void);
+int mgp_create(mgp_handle** out, int device);
+int mgp_destroy(mgp_handle* h);
+int mgp_set_stream(mgp_handle* h, void* hip_stream);
+const char* mgp_last_error(mgp_handle* h);
+/* name of the gfx arch the device code was built for, e.g. "gfx950" */
+const char* mgp_build_arch(void);
+
+/* ---- matrix-free kernel products --------------------------
+ * out[N,R] = k(X,Z) V      replaces Kuf(...)^T @ a, cggp/models.py:334,351 (and :273,:157)
+ * V, out layouts given by v_layout / out_layout (MGP_COLS: [M,R]/[N,R]; MGP_ROWS: [R,M]/[R,N]). */
+int mgp_knm_matvec(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                   int64_t M, const void* V, int32_t R, int v_layout, void* out, int out_layout);
+/* out[M,R] = k(Z,X) W = K_nm^T W   (W [N,R]); deterministic two-stage reduction over row
+ * blocks (no float atomics).  The transpose product of models.py:343 / the SGPR A A^T term. */
+int mgp_kmn_matvec(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                   int64_t M, const void* W, int32_t R, int w_layout, void* out, int out_layout);
+/* out[na, ld>=nb] = k(A,B) (+ jitter on the diagonal, + diag_add[i] on the diagonal when
+ * non-NULL).  Replaces gpflow Kuu/Kuf + add_diagonal: models.py:300-301,333-337, utils.py:11-17. */
+int mgp_k_dense(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B,
+                int64_t nb, void* out, int64_t ld, double jitter, const void* diag_add);
+/* out[M,M] = K_mn K_nm = k(Z,X) k(X,Z): fp64 MFMA contraction, K row panels generated on the
+ * fly (row S1: GPflow SGPR's A A^T, 2 N M^2 flop). */
+int mgp_kmn_knm(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                int64_t M, void* out);
+
+/* ---- dense symmetric product (row M2: `state.p @ A`, conjugate_gradient.py:65) ---------
+ * out[Bt,n] = P[Bt,n] @ A[n,n] for SYMMETRIC A (CG requires it; computed as rows of A dotted
+ * with p_b, i.e. P @ A^T). */
+int mgp_symm_matmul(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P,
+                    int64_t Bt, void* out);
+
+/* ---- preconditioned batched CG (rows CG1, CG3-CG5) -------------------------------------
+ * Solves V A = B for row batches B [Bt,n] starting from V0 (NULL = zeros), exactly the
+ * recurrence of conjugate_gradient.py:59-98: stop when all_b(0.5||r_b||^2 <= thr) or
+ * i >= max_iterations; gamma = 0 where p.Ap <= min_float; beta-term = 0 where rz <= min_float;
+ * residual refresh + direction restart when i % max_steps_cycle == max_steps_cycle-1.
+ * err_out [Bt] receives 0.5*rz_final (stats_error, :97).  check_every = iterations enqueued
+ * between convergence polls (device-side gating keeps the step count exact). */
+int mgp_pcg_solve(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, const void* B,
+                  const void* V0, int64_t Bt, double error_threshold, int64_t max_iterations,
+                  int64_t max_steps_cycle, double min_float, int32_t check_every, void* V_out,
+                  void* err_out, mgp_cg_stats* stats);
+/* one application of an operator: out[Bt,n] = P[Bt,n] @ Op (used by tests and the bench) */
+int mgp_operator_apply(mgp_handle* h, const mgp_operator* op, const void* P, int64_t Bt, void* out);
+
+/* ---- reductions used by the model surface ----------------------------------------------
+ * out[c] = sum_r A[r,c]*B[r,c] (axis 0, like tf.reduce_sum(Kmn * W, axis=0), models.py:343) */
+int mgp_colwise_dot(mgp_handle* h, int dtype, const void* A, const void* B, int64_t rows,
+                    int64_t cols, void* out);
+/* *out = sum(A*B) over count elements (host double); Hutchinson trace, models.py:313 */
+int mgp_dot_all(mgp_handle* h, int dtype, const void* A, const void* B, int64_t count, double* out);
+
+/* ---- next row F1: nearest-centre assignment + cluster statistics (optimize.py:41-98) ----
+ * idx[i] = argmin_m d(Z_m, X_i) (first index on ties), dist type 0 = squared euclidean on raw
+ * inputs (ops.square_distance, optimize.py:50), 1 = euclidean (distance.py:9-11, same argmin),
+ * 2 = covariance, 3 = correlation (distance.py:15-30; kernel required).  best[i] = the distance.
+ * sums[M], counts[M] accumulate y and 1 per cluster in deterministic order. */
+int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const void* X, int64_t N,
+                       const void* Z, int64_t M, int64_t* idx, void* best);
+int mgp_cluster_stats(mgp_handle* h, int dtype, const int64_t* idx, const void* y, int64_t N,
+                      int64_t M, void* sums, void* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGP_H */
