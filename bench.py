@@ -1,0 +1,192 @@
+"""bench.py -- CG iterations/s of the matrix-free SGPR normal-equation solve on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU
+over RCCL.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json `metric`: "CG iters/sec & K_nm.v achieved-HBM-GB/s, N=1M M=4096 D=8 fp64"):
+config C3 -- N = 2^20 rows, D = 8, M = 4096, SE kernel, fp64, synthetic inputs of SURVEY §8(d).
+A step is ONE iteration of the preconditioned CG loop of cggp/conjugate_gradient.py:64-85 on the
+system  S alpha = K_mn y,  S = s2 (Kmm + jitter I) + K_mn K_nm  applied matrix-free:
+one fused K_nm.p sweep, one fused K_mn.u sweep, the replicated dense Kmm.p product, one
+all-reduce of the [1, M] partial (N > 1), and the fused vector update -- all inside libmgp.
+The rows of X are sharded over the ranks (strong scaling: N is the TOTAL row count).
+Inputs are resident in HBM before the timed region.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "conjugate-gradient-sparse-gp_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet (== fp64 matrix peak); MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cggp import _hip, kernels, ops, parallel, synthetic
+    from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
+
+    N, D, M, dtype_name, kname = synthetic.CONFIGS[args.config]
+    tdtype = torch.float64 if dtype_name == "float64" else torch.float32
+    esize = 8 if dtype_name == "float64" else 4
+    syn = synthetic.make_inputs(N, D, M, dtype_name)
+    lo, hi = parallel.shard_bounds(N, world, rank)
+    X = torch.from_numpy(syn.X[lo:hi]).to(dev)
+    y = torch.from_numpy(syn.y[lo:hi]).to(dev)
+    Z = torch.from_numpy(syn.Z).to(dev)
+    n_local = hi - lo
+    kern = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname](
+        variance=syn.variance, lengthscales=syn.lengthscales)
+    spec = kern.spec(D)
+    allreduce = parallel.make_allreduce()
+    op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1)
+    rhs = ops.kmn_matvec(spec, X, Z, y)  # K_mn y  [M,1]
+    if allreduce is not None:
+        allreduce(rhs.view(-1))
+    rhs_rows = rhs.t().contiguous()  # [1, M]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run_steps(k):
+        # error_threshold 0 is never met, so exactly k iterations run (device gating keeps count)
+        _, (steps, _) = conjugate_gradient(op, rhs_rows, None, 0.0, max_iterations=k, max_steps_cycle=k + 1,
+                                           check_every=k)
+        assert int(steps) == k, (int(steps), k)
+
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- dominant kernel: the fused sweep (K_nm.p and K_mn.u are the same kernel symbol),
+    # HIP events bracketing every launch of it over a second pass of the same K steps
+    hd = _hip.get_handle(dev)
+    hd.check(hd.lib.mgp_profile_enable(hd.h, 1))
+    run_steps(args.steps)
+    import ctypes
+    launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+    hd.check(hd.lib.mgp_profile_read(hd.h, ctypes.byref(launches), ctypes.byref(total_ms)))
+    hd.check(hd.lib.mgp_profile_enable(hd.h, 0))
+    sweep_ms = total_ms.value / max(1, launches.value)
+    R = 1
+    flops_launch = float(n_local) * M * FLOPS_PER_PAIR(D, R)
+    bytes_launch = float(esize) * (n_local * D + M * D + M * R + n_local * R)
+    ach_tflops = flops_launch / (sweep_ms * 1e-3) / 1e12
+    ach_gbps = bytes_launch / (sweep_ms * 1e-3) / 1e9
+    equiv_gemv_gbps = float(esize) * n_local * M / (sweep_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.config}/gpus{world}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- bounded convergence report (informational): real stopping rule, thr = 1e-6
+    conv = None
+    if rank == 0 or world > 1:
+        cap = 300
+        sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, max_iterations=cap, max_steps_cycle=cap + 1,
+                                               check_every=25)
+        torch.cuda.synchronize()
+        conv = {"error_threshold": 1e-6, "iteration_cap": cap, "iterations": int(steps),
+                "half_rz_final": float(err.max().item())}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline
+        ns = min(N, args.cpu_sample_rows)
+        sec, threads = cpu_baseline.time_cg_iteration(syn.X[:ns], syn.Z, syn.variance, syn.lengthscales,
+                                                      syn.noise_variance, kname,
+                                                      torch.float64 if esize == 8 else torch.float32)
+        cpu = {"value": 1.0 / (sec * (N / ns)), "unit": "CG iters/s", "cores": threads, "kind": "port",
+               "sample": f"one CG iteration of the same operator on the first {ns} of {N} rows (dense "
+                         f"chunked K build + GEMV, torch-CPU fp{esize * 8}), {sec:.2f} s, scaled by N/sample"}
+
+    if rank == 0:
+        out = {
+            "metric": "CG iters/sec (matrix-free SGPR-CG, N=2^20 M=4096 D=8 fp64)" if args.config == "C3"
+                      else f"CG iters/sec ({args.config})",
+            "value": args.steps / elapsed,
+            "unit": "CG iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if esize == 8 else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: CG on S=s2(Kmm+jI)+KmnKnm, K_nm matrix-free, {kname} kernel",
+                       "N": N, "D": D, "M": M, "rhs": 1, "rows_per_gpu": n_local,
+                       "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M] per step"},
+            "roofline": {
+                "bound": "fp64-valu (the fused sweep is VALU-issue bound, not HBM/MFMA: SURVEY 8d, DESIGN.md)",
+                "kernel": "sweep_kernel<double,8,SE,1> (K_nm.p and K_mn.u)",
+                "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                "flop_per_pair": FLOPS_PER_PAIR(D, R), "pairs_per_launch": float(n_local) * M,
+                "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value),
+                "traffic": traffic,
+                "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_launch,
+                        "equiv_dense_gemv_GBps_derived": equiv_gemv_gbps},
+            },
+            "cpu_baseline": cpu,
+            "convergence": conv,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,10 @@ extern "C" int mgp_destroy(mgp_handle* h) {
   if (h->cg) (void)hipFree(h->cg);
   if (h->opws) (void)hipFree(h->opws);
   if (h->host_flag) (void)hipHostFree(h->host_flag);
+  for (auto& pr : h->prof_ev) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   delete h;
   return MGP_OK;
 }
@@ -42,6 +46,28 @@ extern "C" int mgp_set_stream(mgp_handle* h, void* hip_stream) {
 }
 
 extern "C" const char* mgp_last_error(mgp_handle* h) { return h ? h->err : "invalid handle"; }
+
+extern "C" int mgp_profile_enable(mgp_handle* h, int on) {
+  if (!h) return MGP_E_BADARG;
+  h->prof_on = on != 0;
+  h->prof_used = 0;
+  return MGP_OK;
+}
+
+extern "C" int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms) {
+  if (!h || !launches || !total_ms) return MGP_E_BADARG;
+  MGP_HIP(h, hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0.f;
+    MGP_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[i].first, h->prof_ev[i].second));
+    tot += ms;
+  }
+  *launches = (int64_t)h->prof_used;
+  *total_ms = tot;
+  h->prof_used = 0;
+  return MGP_OK;
+}
 
 namespace {
 

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/mgp.h"
 #include "mgp_math.h"
@@ -26,7 +28,27 @@ struct mgp_handle {
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   int num_cus = 256;
+  // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
 };
+
+// returns the stop event to record after the launch (nullptr when profiling is off)
+inline hipEvent_t mgp_prof_begin(mgp_handle* h) {
+  if (!h->prof_on) return nullptr;
+  if (h->prof_used == h->prof_ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+    h->prof_ev.emplace_back(a, b);
+  }
+  auto& pr = h->prof_ev[h->prof_used++];
+  (void)hipEventRecord(pr.first, h->stream);
+  return pr.second;
+}
+inline void mgp_prof_end(mgp_handle* h, hipEvent_t stop) {
+  if (stop) (void)hipEventRecord(stop, h->stream);
+}
 
 inline int mgp_fail(mgp_handle* h, int code, const char* fmt, ...) {
   if (h) {

@@ -163,17 +163,21 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   if (nchunks > 65535) return mgp_fail(h, MGP_E_SHAPE, "sweep: too many chunks");
   dim3 grid((unsigned)nblk, (unsigned)nchunks);
   if (nchunks == 1) {
+    hipEvent_t stop = mgp_prof_begin(h);
     hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                        b_chunk, W, w_sj, w_sr, out, o_si, o_sr, 0L, D, prm, alpha, addend, ad_si, ad_sr, gate);
+    mgp_prof_end(h, stop);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;
   }
   const size_t need = (size_t)nchunks * na * RC * sizeof(T);
   MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, need));
   T* part = (T*)h->ws;
+  hipEvent_t stop = mgp_prof_begin(h);
   hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                      b_chunk, W, w_sj, w_sr, part, 1L, na, na * (long)RC, D, prm, (T)0, (const T*)nullptr, 0L,
                      0L, gate);
+  mgp_prof_end(h, stop);
   MGP_LAUNCH_CHECK(h);
   const long tot = na * RC;
   hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,

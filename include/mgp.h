@@ -173,6 +173,13 @@ int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const 
 int mgp_cluster_stats(mgp_handle* h, int dtype, const int64_t* idx, const void* y, int64_t N,
                       int64_t M, void* sums, void* counts);
 
+/* ---- measurement (bench.py): HIP events around every launch of the fused sweep kernel ------
+ * While enabled, each sweep launch is bracketed by two events on the handle's stream;
+ * mgp_profile_read synchronises the stream, returns the number of bracketed launches and the
+ * sum of their durations in milliseconds, and resets the counters. */
+int mgp_profile_enable(mgp_handle* h, int on);
+int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif
