@@ -31,7 +31,12 @@ import torch.distributed as dist  # noqa: E402
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet (== fp64 matrix peak); MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
+SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
+# What csrc/sweep.hip executes per pair for the SE kernel (DESIGN.md "kernel 1"): distance D fma + 1 add;
+# exp2 by table: max, 3 add, 2 fma, mul, fma, ldexp (9 fp64 instr, 12 flop) + and/ashr/lshl; RC accumulate fma
+EXEC_FLOPS_PER_PAIR = lambda D, R: (2 * D + 1) + 12 + 2 * R
+EXEC_VALU_INSTR_PER_PAIR = lambda D, R: (D + 1) + 9 + 3 + R
+NUM_SIMDS, MAX_CLOCK_HZ, FP64_CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
 
 
 def main():
@@ -114,7 +119,10 @@ def main():
     hd.check(hd.lib.mgp_profile_enable(hd.h, 0))
     sweep_ms = total_ms.value / max(1, launches.value)
     R = 1
-    flops_launch = float(n_local) * M * FLOPS_PER_PAIR(D, R)
+    pairs_launch = float(n_local) * M
+    flops_launch = pairs_launch * EXEC_FLOPS_PER_PAIR(D, R)
+    issue_s = (pairs_launch / 64.0) * EXEC_VALU_INSTR_PER_PAIR(D, R) * FP64_CYCLES_PER_WAVE_INSTR / (
+        NUM_SIMDS * MAX_CLOCK_HZ)
     bytes_launch = float(esize) * (n_local * D + M * D + M * R + n_local * R)
     ach_tflops = flops_launch / (sweep_ms * 1e-3) / 1e12
     ach_gbps = bytes_launch / (sweep_ms * 1e-3) / 1e9
@@ -169,10 +177,15 @@ def main():
                        "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M] per step"},
             "roofline": {
                 "bound": "fp64-valu (the fused sweep is VALU-issue bound, not HBM/MFMA: SURVEY 8d, DESIGN.md)",
-                "kernel": "sweep_kernel<double,8,SE,1> (K_nm.p and K_mn.u)",
+                "kernel": "sweep_kernel<double,8,SE,1> (K_nm.p and K_mn.u are the same symbol)",
                 "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS,
-                "flop_per_pair": FLOPS_PER_PAIR(D, R), "pairs_per_launch": float(n_local) * M,
+                "flop_per_pair": EXEC_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
+                "valu_instr_per_pair": EXEC_VALU_INSTR_PER_PAIR(D, R),
+                "valu_issue_frac_at_2.4GHz": issue_s / (sweep_ms * 1e-3),
+                "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
+                "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
+                                             / FP64_VECTOR_PEAK_TFLOPS,
                 "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value),
                 "traffic": traffic,
                 "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

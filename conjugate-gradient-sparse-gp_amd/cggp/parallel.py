@@ -37,7 +37,14 @@ def make_allreduce(group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None
 
+    host_staged = dist.get_backend(group) == "gloo"
+
     def _allreduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if host_staged and t.is_cuda:  # gloo rehearsal of the N > 1 path on a single-GPU box
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return _allreduce

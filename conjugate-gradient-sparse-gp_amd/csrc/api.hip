@@ -1,4 +1,6 @@
 // api.hip -- handle lifecycle and the small reductions of the model surface.
+#include <cstdlib>
+
 #include "mgp_common.h"
 
 extern "C" int mgp_version(void) { return MGP_VERSION; }
@@ -16,6 +18,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   h->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+  const char* mode = getenv("MGP_SWEEP");
+  if (mode && strcmp(mode, "mfma") == 0) h->sweep_mode = 1;
   if (hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault) != hipSuccess) {
     delete h;
     return MGP_E_NOMEM;

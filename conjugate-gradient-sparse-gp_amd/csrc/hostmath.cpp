@@ -20,4 +20,13 @@ void mgp_host_profile(int kind, const double* s, double* out, long n) {
   }
 }
 double mgp_host_profile_scale(int kind) { return mgp_profile_scale(kind); }
+void mgp_host_exp2_tab(const double* t, double* out, long n) {
+  static double tab[MGP_EXP2_TAB_SIZE];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < MGP_EXP2_TAB_SIZE; ++i) tab[i] = mgp_exp2_tab_entry(i);
+    init = true;
+  }
+  for (long i = 0; i < n; ++i) out[i] = mgp_exp2_tab(t[i], tab);
+}
 }

@@ -28,6 +28,9 @@ struct mgp_handle {
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   int num_cus = 256;
+  // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
+  // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
+  int sweep_mode = 0;
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -142,5 +145,8 @@ inline VecViewMut mgp_view_mut(void* p, int64_t n, int64_t R, int layout) {
 // out(i,r) = variance * sum_j k(a_i, b_j) w(j,r) [+ alpha * addend(i,r)];  gate: device int, skip if 0
 int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
               VecView W, int32_t R, VecViewMut out, double alpha, VecView addend, const int* gate);
+int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long na, const double* B, long nb,
+                       const double* W, long w_sj, long w_sr, int R, double* out, long o_si, long o_sr,
+                       double alpha, const double* addend, long ad_si, long ad_sr, const int* gate);
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
                           void* out, const int* gate);

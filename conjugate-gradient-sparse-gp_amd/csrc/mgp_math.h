@@ -39,6 +39,33 @@ MGP_HD double mgp_exp2(double t) {
   return __builtin_ldexp(p, (int)nc);
 }
 
+// Table form used by the fused sweeps (the polynomial above costs 11 dependent fp64 fmas per
+// pair, and the sweeps are fp64-VALU bound).  t = n + i/2048 + g with |g| <= 2^-12:
+//   u = t + 1.5*2^41 leaves m = round(2048 t) in the low mantissa word (two's complement), so
+//   i = m & 2047, n = m >> 11 (floor) and g = t - (u - 1.5*2^41) exactly; then
+//   2^t = ldexp(T[i] * (1 + g(c1 + g(c2 + g c3))), n),  T[i] = 2^(i/2048), c_k = ln2^k/k!.
+// Truncation error (g ln2)^4/24 <= 3.4e-17.  8 fp64 instructions + 3 integer ones.
+// `tab` is a 2048-entry table (LDS in the kernels) filled by mgp_exp2_tab_entry().
+#define MGP_EXP2_TAB_BITS 11
+#define MGP_EXP2_TAB_SIZE 2048
+
+MGP_HD double mgp_exp2_tab_entry(int i) { return mgp_exp2((double)i * (1.0 / MGP_EXP2_TAB_SIZE)); }
+
+MGP_HD double mgp_exp2_tab(double t, const double* tab) {
+  t = __builtin_fmax(t, -2000.0);  // keeps m inside int32 for absurdly distant points; 2^-2000 == 0
+  const double C = 0x1.8p+41;
+  const double u = t + C;
+  long long bits;
+  __builtin_memcpy(&bits, &u, sizeof(bits));
+  const int m = (int)bits;
+  const double g = t - (u - C);
+  double q = __builtin_fma(g, 0x1.c6b08d704a0c0p-5, 0x1.ebfbdff82c58fp-3);  // ln2^3/6, ln2^2/2
+  q = __builtin_fma(q, g, 0x1.62e42fefa39efp-1);                              // ln2
+  q = q * g;
+  const double T = tab[m & (MGP_EXP2_TAB_SIZE - 1)];
+  return __builtin_ldexp(__builtin_fma(T, q, T), m >> MGP_EXP2_TAB_BITS);
+}
+
 MGP_HD float mgp_exp2(float t) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_exp2f(t);  // v_exp_f32, 1 ulp
@@ -71,15 +98,26 @@ inline double mgp_profile_scale(int kind) {
 
 // neg_s = 2 a.b - |a|^2 - |b|^2 = -s (the expansion form GPflow's square_distance uses).
 // clamp = c^2 * 1e-36 (GPflow's floor under the sqrt, in scaled units).
-template <int KIND, typename T>
-MGP_HD T mgp_profile(T neg_s, T clamp) {
+// exp2 provider: E2Poly evaluates the polynomial (or v_exp_f32), E2Tab<double> reads the table
+struct E2Poly {
+  MGP_HD double operator()(double t) const { return mgp_exp2(t); }
+  MGP_HD float operator()(float t) const { return mgp_exp2(t); }
+};
+struct E2Tab {
+  const double* tab;
+  MGP_HD double operator()(double t) const { return mgp_exp2_tab(t, tab); }
+  MGP_HD float operator()(float t) const { return mgp_exp2(t); }
+};
+
+template <int KIND, typename T, typename E2 = E2Poly>
+MGP_HD T mgp_profile(T neg_s, T clamp, E2 e2 = E2()) {
   if (KIND == 0) {
-    return mgp_exp2(neg_s);
+    return e2(neg_s);
   } else {
     T s = -neg_s;
     s = s > clamp ? s : clamp;
     const T q = mgp_sqrt(s);
-    const T e = mgp_exp2(-q);
+    const T e = e2(-q);
     if (KIND == 1) return e;
     if (KIND == 2) return mgp_fma(q, (T)MGP_LN2, (T)1.0) * e;
     const T c2 = (T)(MGP_LN2 * MGP_LN2 / 3.0);

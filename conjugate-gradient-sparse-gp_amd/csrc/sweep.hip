@@ -21,7 +21,8 @@ namespace {
 template <int DP>
 struct TileCfg {
   static constexpr int TB = DP <= 8 ? 256 : (DP <= 16 ? 128 : 64);  // broadcast points per LDS tile
-  static constexpr int RPT = DP <= 4 ? 4 : (DP <= 16 ? 2 : 1);      // owned points per lane
+  static constexpr int RPT = DP <= 8 ? 4 : (DP <= 16 ? 2 : 1);      // owned points per lane
+  static constexpr int UJ = RPT >= 4 ? 1 : 2;                        // streamed points per loop trip
 };
 
 constexpr int kThreads = 256;
@@ -35,11 +36,18 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   if (gate != nullptr && *gate == 0) return;
   constexpr int TB = TileCfg<DP>::TB;
   constexpr int RPT = TileCfg<DP>::RPT;
+  constexpr int UJ = TileCfg<DP>::UJ;
   constexpr int PS = (DP + 1 + RC + 1) & ~1;  // per-point LDS stride, even => 16-B aligned rows
   __shared__ __attribute__((aligned(16))) T tile[TB * PS];
+  // fp64: 2^(i/2048) table for mgp_exp2_tab (16 KB); fp32 uses v_exp_f32 and no table
+  __shared__ double e2tab[sizeof(T) == 8 ? MGP_EXP2_TAB_SIZE : 1];
 
   const int t = threadIdx.x;
   const long base = (long)blockIdx.x * (kThreads * RPT);
+  if (sizeof(T) == 8) {
+    for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreads) e2tab[e] = mgp_exp2_tab_entry(e);
+  }
+  const E2Tab e2{e2tab};  // first use is behind the tile loop's barriers
 
   // ---- owned points: scaled coordinates and squared norm in registers
   T a[RPT][DP];
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
     }
     __syncthreads();
 
-#pragma unroll 2
+#pragma unroll UJ
     for (int jj = 0; jj < TB; ++jj) {
       const T* p = &tile[jj * PS];
       T b[DP];
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
         T s = nb2 - a2[q];
 #pragma unroll
         for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
-        const T kv = mgp_profile<KIND, T>(s, clamp);
+        const T kv = mgp_profile<KIND, T, E2Tab>(s, clamp, e2);
 #pragma unroll
         for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
       }
@@ -126,22 +134,36 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   }
 }
 
-// out(i,r) = sum_c partial[c][r][i] (+ alpha*addend), chunks summed in index order
+// out(i,r) = sum_c partial[c][r][i] (+ alpha*addend).  Block = 16 groups x 64 columns: group g
+// sums chunks g, g+16, ... in index order, the 16 group sums are added in a fixed tree -- the
+// result does not depend on scheduling (deterministic, no float atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const T* __restrict__ part, long na, int R,
-                                                              int nchunks, T* __restrict__ out, long o_si,
-                                                              long o_sr, T alpha, const T* __restrict__ addend,
-                                                              long ad_si, long ad_sr,
-                                                              const int* __restrict__ gate) {
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restrict__ part, long na, int R,
+                                                               int nchunks, T* __restrict__ out, long o_si,
+                                                               long o_sr, T alpha, const T* __restrict__ addend,
+                                                               long ad_si, long ad_sr,
+                                                               const int* __restrict__ gate) {
   if (gate != nullptr && *gate == 0) return;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= na * R) return;
-  const long r = idx / na, i = idx - r * na;
-  T s = 0;
+  __shared__ T red[16][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + col;
   const long stride = na * R;
-  for (int c = 0; c < nchunks; ++c) s += part[(long)c * stride + idx];
-  if (addend != nullptr) s = mgp_fma(alpha, addend[i * ad_si + r * ad_sr], s);
-  out[i * o_si + r * o_sr] = s;
+  T s = 0;
+  if (idx < stride) {
+#pragma unroll 4
+    for (int c = grp; c < nchunks; c += 16) s += part[(long)c * stride + idx];
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && idx < stride) {
+    T t8[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t8[g] = red[2 * g][col] + red[2 * g + 1][col];
+    T v = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+    const long r = idx / na, i = idx - r * na;
+    if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si + r * ad_sr], v);
+    out[i * o_si + r * o_sr] = v;
+  }
 }
 
 template <typename T, int DP, int KIND, int RC>
@@ -152,8 +174,10 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   constexpr int RPT = TileCfg<DP>::RPT;
   const long per_block = (long)kThreads * RPT;
   const long nblk = (na + per_block - 1) / per_block;
+  // enough workgroups to fill the chip: none of the streamed set is split when the owned side
+  // already gives >= 4 workgroups per CU, else aim for ~8 per CU
   const long target = 8L * h->num_cus;
-  long nchunks = (target + nblk - 1) / nblk;
+  long nchunks = nblk >= 4L * h->num_cus ? 1 : (target + nblk - 1) / nblk;
   const long max_chunks = (nb + TB - 1) / TB;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
@@ -180,7 +204,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   mgp_prof_end(h, stop);
   MGP_LAUNCH_CHECK(h);
   const long tot = na * RC;
-  hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+  hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((tot + 63) / 64)), dim3(1024), 0, h->stream,
                      part, na, RC, (int)nchunks, out, o_si, o_sr, alpha, addend, ad_si, ad_sr, gate);
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;
@@ -267,6 +291,10 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
     // empty sum: out = alpha*addend (or 0); rare path, handled by a 1-chunk sweep over a dummy tile
     return mgp_fail(h, MGP_E_SHAPE, "empty broadcast set");
   }
+  if (k->dtype == MGP_F64 && h->sweep_mode == 1)
+    return mgp_sweep_mfma_f64(h, k, (const double*)A, na, (const double*)B, nb, (const double*)W.base, W.si, W.sr,
+                              R, (double*)out.base, out.si, out.sr, alpha, (const double*)addend.base, addend.si,
+                              addend.sr, gate);
   if (k->dtype == MGP_F64)
     return sweep_kind<double>(h, k, (const double*)A, na, (const double*)B, nb, (const double*)W.base, W.si,
                               W.sr, R, (double*)out.base, out.si, out.sr, alpha, (const double*)addend.base,

@@ -6,7 +6,7 @@ through GPflow's `square_distance` expansion + exp (gpflow/utilities/ops.py,
 gpflow/kernels/stationaries.py), then GEMV/GEMM against it -- exactly what
 `cggp/models.py:334,351` (`Kuf` then `matmul`) and the dense `p @ A` of
 `cggp/conjugate_gradient.py:65` do -- in torch-CPU with every host core
-(`torch.set_num_threads(os.cpu_count())`), as BASELINE.md §3 prescribes.
+(the cores this process may use: cgroup quota / affinity), as BASELINE.md §3 prescribes.
 """
 
 import os
@@ -45,7 +45,8 @@ def sgpr_operator_apply(X, Z, v, Kmm, s2, variance, lengthscales, name="se", chu
 def time_cg_iteration(X, Z, variance, lengthscales, s2, name="se", dtype=torch.float64, repeats=2):
     """Seconds for ONE CG iteration of the SGPR normal-equation operator on the given rows
     (operator application + the vector updates of conjugate_gradient.py:66-84), best of repeats."""
-    threads = os.cpu_count() or 1
+    from .hostinfo import available_cores
+    threads = available_cores()  # cgroup/affinity share of the box, not the raw socket count
     torch.set_num_threads(threads)
     X = torch.from_numpy(np.ascontiguousarray(X)).to(dtype)
     Z = torch.from_numpy(np.ascontiguousarray(Z)).to(dtype)

@@ -69,10 +69,13 @@ def test_knm_kmn_matvec_fp64(name, D):
     V, W = rng.standard_normal((M, R)), rng.standard_normal((N, R))
     K = ko.K(X, Z)
     spec = k.spec(D)
+    # Matern12 = exp(-sqrt(r2)) has a cusp at 0: in 1-D some of the 77000 pairs are nearly
+    # coincident and the rounding of GPflow's r2 expansion shows through the sqrt (reference too)
+    tol = 1e-11 if name != "matern12" else 1e-9
     out = ops.knm_matvec(spec, T(X), T(Z), T(V))
-    assert out.shape == (N, R) and relerr(out, K @ V) < 1e-11
+    assert out.shape == (N, R) and relerr(out, K @ V) < tol
     out_t = ops.kmn_matvec(spec, T(X), T(Z), T(W))
-    assert out_t.shape == (M, R) and relerr(out_t, K.T @ W) < 1e-11
+    assert out_t.shape == (M, R) and relerr(out_t, K.T @ W) < tol
 
 
 @pytest.mark.parametrize("R", [1, 2, 4, 5, 8, 13])
