@@ -32,8 +32,23 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
     const T* __restrict__ A, long na, const T* __restrict__ B, long nb, long b_chunk,
     const T* __restrict__ W, long w_sj, long w_sr, T* __restrict__ out, long o_si, long o_sr,
     long o_chunk, int D, SweepParams prm, T alpha, const T* __restrict__ addend, long ad_si,
-    long ad_sr, const int* __restrict__ gate) {
+    long ad_sr, const int* __restrict__ gate, int nblk, int nchunks) {
   if (gate != nullptr && *gate == 0) return;
+  // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so the
+  // nblk workgroups that stream the SAME chunk of broadcast points get linear ids that differ by
+  // multiples of 8 (same XCD, dispatched together) and share the chunk through that XCD's L2.
+  // Placement only changes speed/traffic, never the result.
+  // Only when the chunk count is a multiple of 8 (otherwise the plain decode keeps all XCDs busy).
+  const int lin = blockIdx.x;
+  int bx, by;
+  if ((nchunks & 7) == 0) {
+    const int grp = lin / (8 * nblk), rem = lin - grp * (8 * nblk);
+    bx = rem >> 3;
+    by = grp * 8 + (rem & 7);
+  } else {
+    by = lin / nblk;
+    bx = lin - by * nblk;
+  }
   constexpr int TB = TileCfg<DP>::TB;
   constexpr int RPT = TileCfg<DP>::RPT;
   constexpr int UJ = TileCfg<DP>::UJ;
@@ -43,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   __shared__ double e2tab[sizeof(T) == 8 ? MGP_EXP2_TAB_SIZE : 1];
 
   const int t = threadIdx.x;
-  const long base = (long)blockIdx.x * (kThreads * RPT);
+  const long base = (long)bx * (kThreads * RPT);
   if (sizeof(T) == 8) {
     for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreads) e2tab[e] = mgp_exp2_tab_entry(e);
   }
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
     for (int r = 0; r < RC; ++r) acc[q][r] = 0;
   }
 
-  const long jb = (long)blockIdx.y * b_chunk;
+  const long jb = (long)by * b_chunk;
   const long je = (jb + b_chunk < nb) ? jb + b_chunk : nb;
   const T clamp = (T)prm.clamp;
 
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   }
 
   const T var = (T)prm.variance;
-  T* o = out + (long)blockIdx.y * o_chunk;
+  T* o = out + (long)by * o_chunk;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const long i = base + q * kThreads + t;
@@ -185,11 +200,13 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   b_chunk = (b_chunk + TB - 1) / TB * TB;
   nchunks = (nb + b_chunk - 1) / b_chunk;
   if (nchunks > 65535) return mgp_fail(h, MGP_E_SHAPE, "sweep: too many chunks");
-  dim3 grid((unsigned)nblk, (unsigned)nchunks);
+  if (nblk * nchunks > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "sweep: grid too large");
+  dim3 grid((unsigned)(nblk * nchunks));
   if (nchunks == 1) {
     hipEvent_t stop = mgp_prof_begin(h);
     hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
-                       b_chunk, W, w_sj, w_sr, out, o_si, o_sr, 0L, D, prm, alpha, addend, ad_si, ad_sr, gate);
+                       b_chunk, W, w_sj, w_sr, out, o_si, o_sr, 0L, D, prm, alpha, addend, ad_si, ad_sr, gate, (int)nblk,
+                       (int)nchunks);
     mgp_prof_end(h, stop);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;
@@ -200,7 +217,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   hipEvent_t stop = mgp_prof_begin(h);
   hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                      b_chunk, W, w_sj, w_sr, part, 1L, na, na * (long)RC, D, prm, (T)0, (const T*)nullptr, 0L,
-                     0L, gate);
+                     0L, gate, (int)nblk, (int)nchunks);
   mgp_prof_end(h, stop);
   MGP_LAUNCH_CHECK(h);
   const long tot = na * RC;

@@ -1,0 +1,102 @@
+"""BASELINE.json's full sizes on the GPU, through size-independent properties (the oracle cannot
+finish N x M = 4e9 pairs in seconds): spot rows against the oracle, adjointness, linearity,
+shard-sum invariance, symmetry/positivity of the SGPR operator, ragged N."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernels as ok
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def setup(cfg):
+    from cggp import kernels, synthetic
+    N, D, M, dt, kname = synthetic.CONFIGS[cfg]
+    syn = synthetic.make_inputs(N, D, M, dt, need_y=False)
+    tdt = torch.float64 if dt == "float64" else torch.float32
+    X, Z = torch.from_numpy(syn.X).to(dev()), torch.from_numpy(syn.Z).to(dev())
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname]
+    kern = cls(1.0, [1.0] * D)
+    return syn, X, Z, kern, ok.Kernel(kname, 1.0, np.ones(D)), tdt
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C3r", "C5"])
+def test_fullsize_kernel_products(cfg):
+    from cggp import ops, synthetic
+    syn, X, Z, kern, ko, tdt = setup(cfg)
+    N, D = syn.X.shape
+    M = syn.Z.shape[0]
+    spec = kern.spec(D)
+    v = torch.from_numpy(synthetic.make_vectors(M, 1)).to(dev())
+    w = torch.from_numpy(np.random.default_rng(5).standard_normal((N, 1))).to(dev())
+    u = ops.knm_matvec(spec, X, Z, v)
+    t = ops.kmn_matvec(spec, X, Z, w)
+    assert u.shape == (N, 1) and t.shape == (M, 1) and torch.isfinite(u).all() and torch.isfinite(t).all()
+    # spot rows / columns against the oracle (incl. the first, the last and ragged-tail rows)
+    rows = np.r_[0, 1, N - 1, N - 2, np.random.default_rng(6).integers(0, N, 60)]
+    ref = ko.K(syn.X[rows], syn.Z) @ v.cpu().numpy()
+    assert np.max(np.abs(u.cpu().numpy()[rows] - ref)) / np.max(np.abs(ref)) < 1e-11
+    cols = np.r_[0, M - 1, np.random.default_rng(7).integers(0, M, 6)]
+    ref_t = np.zeros((len(cols), 1))
+    wn = w.cpu().numpy()
+    for s in range(0, N, 65536):
+        ref_t += ko.K(syn.Z[cols], syn.X[s:s + 65536]) @ wn[s:s + 65536]
+    assert np.max(np.abs(t.cpu().numpy()[cols] - ref_t)) / np.max(np.abs(ref_t)) < 1e-11
+    # adjointness <K v, w> == <v, K^T w>
+    lhs, rhs = ops.dot_all(u, w), ops.dot_all(v, t)
+    assert abs(lhs - rhs) / abs(lhs) < 1e-11
+    # linearity
+    v2 = torch.from_numpy(np.random.default_rng(8).standard_normal((M, 1))).to(dev())
+    u2 = ops.knm_matvec(spec, X, Z, v2)
+    u12 = ops.knm_matvec(spec, X, Z, 2.0 * v - 3.0 * v2)
+    assert float((u12 - (2.0 * u - 3.0 * u2)).abs().max()) / float(u12.abs().max()) < 1e-12
+    # shard-sum invariance of the transpose product (the multi-GPU decomposition, G = 2, 4, 8)
+    for G in (2, 8):
+        per = -(-N // G)
+        acc = torch.zeros_like(t)
+        for g in range(G):
+            acc += ops.kmn_matvec(spec, X[g * per:(g + 1) * per], Z, w[g * per:(g + 1) * per])
+        assert float((acc - t).abs().max()) / float(t.abs().max()) < 1e-12
+    # run-to-run determinism (ordered reductions, no float atomics)
+    assert torch.equal(t, ops.kmn_matvec(spec, X, Z, w))
+
+
+def test_fullsize_sgpr_operator_properties():
+    from cggp import ops, synthetic
+    from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
+    syn, X, Z, kern, ko, tdt = setup("C3")
+    M = syn.Z.shape[0]
+    op = SgprNormalOperator(kern, X, Z, 0.1, jitter=1e-6)
+    rng = np.random.default_rng(9)
+    a = torch.from_numpy(rng.standard_normal((1, M))).to(dev())
+    b = torch.from_numpy(rng.standard_normal((1, M))).to(dev())
+    Sa, Sb = op.rmatmul(a), op.rmatmul(b)
+    assert abs(ops.dot_all(Sa, b) - ops.dot_all(a, Sb)) / abs(ops.dot_all(Sa, b)) < 1e-10  # symmetric
+    assert ops.dot_all(Sa, a) > 0 and ops.dot_all(Sb, b) > 0  # positive definite
+    # exactly K CG steps run and the recurrence residual statistic falls
+    rhs = ops.kmn_matvec(kern.spec(8), X, Z, torch.from_numpy(
+        np.sin(syn.X).sum(1, keepdims=True)).to(dev())).t().contiguous()
+    _, (s0, e0) = conjugate_gradient(op, rhs, None, 0.0, max_iterations=2, check_every=2)
+    _, (s1, e1) = conjugate_gradient(op, rhs, None, 0.0, max_iterations=12, check_every=12)
+    assert int(s0) == 2 and int(s1) == 12 and float(e1) < float(e0)
+
+
+def test_fullsize_fp32_c4_slice():
+    """C4 (N=1e7, D=2, M=8192, fp32) is an 8-GPU config: one rank's 1.25e6-row shard here."""
+    from cggp import kernels, ops, synthetic
+    N, D, M = 1_250_000, 2, 8192
+    syn = synthetic.make_inputs(N, D, M, "float32", need_y=False)
+    X, Z = torch.from_numpy(syn.X).to(dev()), torch.from_numpy(syn.Z).to(dev())
+    kern = kernels.SquaredExponential(1.0, [1.0, 1.0])
+    v = torch.from_numpy(synthetic.make_vectors(M, 1, "float32")).to(dev())
+    u = ops.knm_matvec(kern.spec(D), X, Z, v)
+    rows = np.random.default_rng(1).integers(0, N, 64)
+    ko = ok.Kernel("se", 1.0, np.ones(D))
+    ref = ko.K(syn.X[rows].astype(np.float64), syn.Z.astype(np.float64)) @ v.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(u.cpu().numpy()[rows] - ref)) / np.max(np.abs(ref)) < 2e-4
