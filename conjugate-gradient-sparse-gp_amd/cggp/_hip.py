@@ -104,7 +104,8 @@ SIGNATURES = {
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    # MGP_LIBRARY lets A/B measurements load an experimental build; the default is the in-tree one
+    return os.environ.get("MGP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load_library():

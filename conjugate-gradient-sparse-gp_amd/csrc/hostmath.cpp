@@ -27,6 +27,6 @@ void mgp_host_exp2_tab(const double* t, double* out, long n) {
     for (int i = 0; i < MGP_EXP2_TAB_SIZE; ++i) tab[i] = mgp_exp2_tab_entry(i);
     init = true;
   }
-  for (long i = 0; i < n; ++i) out[i] = mgp_exp2_tab(t[i], tab);
+  for (long i = 0; i < n; ++i) out[i] = mgp_exp2_tab<true>(t[i], tab);
 }
 }

@@ -51,8 +51,11 @@ MGP_HD double mgp_exp2(double t) {
 
 MGP_HD double mgp_exp2_tab_entry(int i) { return mgp_exp2((double)i * (1.0 / MGP_EXP2_TAB_SIZE)); }
 
+// CLAMP = false is only legal when the caller has bounded |t| < 2^20 (the sweeps check
+// 2(max|a|^2 + max|b|^2) per tile and fall back to the clamped loop otherwise).
+template <bool CLAMP = true>
 MGP_HD double mgp_exp2_tab(double t, const double* tab) {
-  t = __builtin_fmax(t, -2000.0);  // keeps m inside int32 for absurdly distant points; 2^-2000 == 0
+  if (CLAMP) t = __builtin_fmax(t, -2000.0);  // keeps m inside int32 for absurdly distant points; 2^-2000 == 0
   const double C = 0x1.8p+41;
   const double u = t + C;
   long long bits;
@@ -103,9 +106,10 @@ struct E2Poly {
   MGP_HD double operator()(double t) const { return mgp_exp2(t); }
   MGP_HD float operator()(float t) const { return mgp_exp2(t); }
 };
+template <bool CLAMP = true>
 struct E2Tab {
   const double* tab;
-  MGP_HD double operator()(double t) const { return mgp_exp2_tab(t, tab); }
+  MGP_HD double operator()(double t) const { return mgp_exp2_tab<CLAMP>(t, tab); }
   MGP_HD float operator()(float t) const { return mgp_exp2(t); }
 };
 

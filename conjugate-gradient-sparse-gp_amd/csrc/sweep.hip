@@ -62,12 +62,14 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   if (sizeof(T) == 8) {
     for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreads) e2tab[e] = mgp_exp2_tab_entry(e);
   }
-  const E2Tab e2{e2tab};  // first use is behind the tile loop's barriers
+  __shared__ T bmax_w[kThreads / 64];  // per-wave max |b|^2 of the staged tile
+  __shared__ T amax_w[kThreads / 64];
 
   // ---- owned points: scaled coordinates and squared norm in registers
   T a[RPT][DP];
   T a2[RPT];
   T acc[RPT][RC];
+  T amax = 0;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     long i = base + q * kThreads + t;
@@ -80,9 +82,16 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
       s = mgp_fma(v, v, s);
     }
     a2[q] = s;
+    amax = s > amax ? s : amax;
 #pragma unroll
     for (int r = 0; r < RC; ++r) acc[q][r] = 0;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T o = __shfl_xor(amax, off, 64);
+    amax = o > amax ? o : amax;
+  }
+  if ((t & 63) == 0) amax_w[t >> 6] = amax;
 
   const long jb = (long)by * b_chunk;
   const long je = (jb + b_chunk < nb) ? jb + b_chunk : nb;
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
 
   for (long j0 = jb; j0 < je; j0 += TB) {
     __syncthreads();  // previous tile fully consumed
+    T bs = 0;
     if (t < TB) {
       const long j = j0 + t;
       T* p = &tile[t * PS];
@@ -102,6 +112,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
           p[d] = v + v;
         }
         p[DP] = -s;
+        bs = s;
 #pragma unroll
         for (int r = 0; r < RC; ++r) p[DP + 1 + r] = W[j * w_sj + r * w_sr];
       } else {
@@ -109,28 +120,48 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
         for (int d = 0; d < DP + 1 + RC; ++d) p[d] = 0;
       }
     }
-    __syncthreads();
-
-#pragma unroll UJ
-    for (int jj = 0; jj < TB; ++jj) {
-      const T* p = &tile[jj * PS];
-      T b[DP];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) b[d] = p[d];
-      const T nb2 = p[DP];
-      T w[RC];
-#pragma unroll
-      for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
-#pragma unroll
-      for (int q = 0; q < RPT; ++q) {
-        T s = nb2 - a2[q];
-#pragma unroll
-        for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
-        const T kv = mgp_profile<KIND, T, E2Tab>(s, clamp, e2);
-#pragma unroll
-        for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
-      }
+    for (int off = 32; off > 0; off >>= 1) {
+      const T o = __shfl_xor(bs, off, 64);
+      bs = o > bs ? o : bs;
     }
+    if ((t & 63) == 0) bmax_w[t >> 6] = bs;
+    __syncthreads();
+    // |t| = |a-b|^2 <= 2(|a|^2 + |b|^2): below 2^19 the exp2 table form needs no clamp
+    T aa = 0, bb = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+      aa = amax_w[w] > aa ? amax_w[w] : aa;
+      bb = bmax_w[w] > bb ? bmax_w[w] : bb;
+    }
+    const bool safe = (T)2 * (aa + bb) < (T)524288;  // NaN inputs compare false -> clamped loop
+
+    auto body = [&](auto e2) {
+#pragma unroll UJ
+      for (int jj = 0; jj < TB; ++jj) {
+        const T* p = &tile[jj * PS];
+        T b[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) b[d] = p[d];
+        const T nb2 = p[DP];
+        T w[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          T s = nb2 - a2[q];
+#pragma unroll
+          for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
+          const T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
+#pragma unroll
+          for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
+        }
+      }
+    };
+    if (safe)
+      body(E2Tab<false>{e2tab});
+    else
+      body(E2Tab<true>{e2tab});
   }
 
   const T var = (T)prm.variance;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kThreadsM) void sweep_mfma_kernel(
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long base = (long)blockIdx.x * OWN;
   for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreadsM) e2tab[e] = mgp_exp2_tab_entry(e);
-  const E2Tab e2{e2tab};
+  const E2Tab<true> e2{e2tab};
 
   // ---- prologue: owned points -> augmented vectors in LDS -> A fragments in registers
   // (OWN * K4 doubles; OWN = 64*TR <= 256, K4 <= 36: fits in frag[] because 16*64 >= OWN)
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreadsM) void sweep_mfma_kernel(
       for (int tr = 0; tr < TR; ++tr)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const double kv = mgp_profile<KIND, double, E2Tab>(c[tr][r4], clamp, e2);
+          const double kv = mgp_profile<KIND, double, E2Tab<true>>(c[tr][r4], clamp, e2);
 #pragma unroll
           for (int r = 0; r < RC; ++r) acc[tr][r4][r] = mgp_fma(kv, w[r], acc[tr][r4][r]);
         }

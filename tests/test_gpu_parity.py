@@ -154,6 +154,31 @@ def test_sweep_coincident_points_and_far_points():
     assert relerr(out, ko.K(X, Z) @ V) < 1e-11
 
 
+def test_sweep_tiny_lengthscale_takes_the_clamped_path():
+    """Scaled distances beyond 2^19 switch the tile to the clamped exp2 loop (no int32 wrap of the
+    table index): everything underflows to 0 except coincident points, which give the variance."""
+    from cggp import kernels, ops
+    D = 8
+    k = kernels.SquaredExponential(variance=1.3, lengthscales=[1e-3] * D)
+    ko = ok.Kernel("se", 1.3, np.full(D, 1e-3))
+    X, Z = points(600, 300, D)
+    X[:300] = Z
+    V = np.random.default_rng(0).standard_normal((300, 2))
+    out = ops.knm_matvec(k.spec(D), T(X), T(Z), T(V))
+    assert torch.isfinite(out).all()
+    # |a|^2 ~ 1e7 in scaled units: the expansion's rounding (eps * |a|^2 ~ 1e-9) is what is left
+    # of r2 = 0 at the coincident points, in the reference's formula as much as here
+    assert relerr(out, ko.K(X, Z) @ V) < 1e-7
+    assert float(out[300:].abs().max()) == 0.0
+    # mixed tile: a few far rows next to ordinary ones
+    k2, ko2 = make_kernel("se", D)
+    X2, Z2 = points(700, 260, D)
+    X2[5] *= 1e4
+    Z2[7] *= 1e4
+    out2 = ops.kmn_matvec(k2.spec(D), T(X2), T(Z2), T(np.ones((700, 1))))
+    assert relerr(out2, ko2.K(X2, Z2).T @ np.ones((700, 1))) < 1e-11
+
+
 # ------------------------------------------------------------------ dense K
 @pytest.mark.parametrize("name", KINDS)
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
