@@ -90,6 +90,7 @@ SIGNATURES = {
     "mgp_kmn_matvec": (_I, [_P, _KP, _P, _L, _P, _L, _P, ctypes.c_int32, _I, _P, _I]),
     "mgp_k_dense": (_I, [_P, _KP, _P, _L, _P, _L, _P, _L, _D, _P]),
     "mgp_kmn_knm": (_I, [_P, _KP, _P, _L, _P, _L, _P]),
+    "mgp_kmn_sq_colsum": (_I, [_P, _KP, _P, _L, _P, _L, _P]),
     "mgp_symm_matmul": (_I, [_P, _I, _P, _L, _P, _L, _P]),
     "mgp_pcg_solve": (_I, [_P, ctypes.POINTER(MgpOperator), ctypes.POINTER(MgpPrecond), _P, _P, _L, _D,
                            _L, _L, _D, ctypes.c_int32, _P, _P, ctypes.POINTER(MgpCgStats)]),

@@ -192,8 +192,11 @@ class SgprNormalOperator(LinearOperator):
         return super().rmatmul(P)
 
     def diag(self):
-        # sum_i k(x_i, z_m)^2 has no fused form yet
-        raise NotImplementedError("diag() of the SGPR operator is not provided; use EyePreconditioner")
+        """diag(S) = s2 diag(Kmm_j) + sum_i k(x_i, z_m)^2 (one fused sweep, summed over ranks)."""
+        d = ops.kmn_sq_colsum(self.spec, self.X, self.Z)
+        if self.allreduce is not None:
+            self.allreduce(d)
+        return d + self.s2 * self.Kmm.diagonal()
 
 
 def as_operator(matrix):

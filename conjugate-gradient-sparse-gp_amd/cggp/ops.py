@@ -121,6 +121,20 @@ def kmn_knm(spec, X, Z):
     return out
 
 
+def kmn_sq_colsum(spec, X, Z):
+    """out [M] = sum_i k(x_i, z_m)^2 = diag(K_mn K_nm)."""
+    X = _points(X, "X", spec.D)
+    Z = _points(Z, "Z", spec.D, X.dtype)
+    M = Z.shape[0]
+    out = torch.empty((M,), dtype=X.dtype, device=X.device)
+    if M == 0:
+        return out
+    hd = _hip.get_handle(X.device)
+    k = spec.struct(_hip.dtype_code(X))
+    hd.check(hd.lib.mgp_kmn_sq_colsum(hd.h, ctypes.byref(k), _hip.ptr(X), X.shape[0], _hip.ptr(Z), M, _hip.ptr(out)))
+    return out
+
+
 def symm_matmul(A, P):
     """out [Bt,n] = P [Bt,n] @ A [n,n] for symmetric A (row M2)."""
     A = _hip.check_tensor(A, "A")

@@ -20,9 +20,20 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
   const char* mode = getenv("MGP_SWEEP");
   if (mode && strcmp(mode, "mfma") == 0) h->sweep_mode = 1;
+  const char* ns = getenv("MGP_NOSPLIT_PER_CU");
+  if (ns && atoi(ns) > 0) h->nosplit_per_cu = atoi(ns);
   if (hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault) != hipSuccess) {
     delete h;
     return MGP_E_NOMEM;
+  }
+  {
+    struct { double d; float f; float pad; } one{1.0, 1.0f, 0.f};
+    if (hipMalloc(&h->ones, 16) != hipSuccess ||
+        hipMemcpy(h->ones, &one, 16, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipHostFree(h->host_flag);
+      delete h;
+      return MGP_E_NOMEM;
+    }
   }
   *out = h;
   return MGP_OK;
@@ -35,6 +46,7 @@ extern "C" int mgp_destroy(mgp_handle* h) {
   if (h->cg) (void)hipFree(h->cg);
   if (h->opws) (void)hipFree(h->opws);
   if (h->host_flag) (void)hipHostFree(h->host_flag);
+  if (h->ones) (void)hipFree(h->ones);
   for (auto& pr : h->prof_ev) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);

@@ -250,9 +250,109 @@ __global__ __launch_bounds__(256) void symm_gemm_kernel(const T* __restrict__ A,
       }
 }
 
+
+// ------------------------------------------------------------------ skinny product (2 <= Bt <= 128)
+// out[Bt, n] = P[Bt, n] . A^T with A streamed from HBM exactly once (bytes s(n^2 + 2 n Bt), the
+// GEMV roofline) and the Bt-wide contraction on the matrix cores.  A workgroup of 8 waves owns 16
+// columns j (= 16 rows of A); wave w takes every 8th 16-wide k slab.  Per slab a lane reads 4
+// consecutive k of its row of A (32 B, whole 128-B lines per 4 lanes) and the matching rows of
+// P^T (P is transposed and zero-padded to 16*NBT columns once per call, so those reads are
+// 128-B segments too); the MFMA K order is permuted consistently on both operands.  The 8 partial
+// tiles are summed through LDS in wave order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ P, long Bt, long n,
+                                                            T* __restrict__ Pt, int BP,
+                                                            const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * BP) return;
+  const long k = e / BP;
+  const int b = (int)(e - k * BP);
+  Pt[e] = b < Bt ? P[(long)b * n + k] : (T)0;
+}
+
+template <typename T, int NBT>
+__global__ __launch_bounds__(512) void symm_skinny_kernel(const T* __restrict__ A, long n,
+                                                          const T* __restrict__ Pt, long Bt,
+                                                          T* __restrict__ out, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int BP = 16 * NBT;
+  using Acc = typename Mfma<T>::Acc;
+  __shared__ T red[8 * NBT * 4 * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int jj = lane & 15, g = lane >> 4;
+  const long j0 = (long)blockIdx.x * 16;
+  const long j = j0 + jj < n ? j0 + jj : n - 1;
+  const T* arow = A + j * n;
+  Acc acc[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
+  const bool vec = (n & 3) == 0;
+  for (long k0 = (long)wave * 16; k0 < n; k0 += 8 * 16) {
+    const long kb = k0 + 4 * g;
+    T a[4];
+    if (vec && kb + 3 < n) {
+      using V4 = __attribute__((ext_vector_type(4))) T;
+      const V4 v = *reinterpret_cast<const V4*>(arow + kb);
+      a[0] = v[0];
+      a[1] = v[1];
+      a[2] = v[2];
+      a[3] = v[3];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = kb + s < n ? arow[kb + s] : (T)0;
+    }
+    T p[NBT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long k = kb + s;
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) p[bt][s] = k < n ? Pt[k * BP + bt * 16 + jj] : (T)0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(p[bt][s], a[s], acc[bt]);
+  }
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * NBT + bt) * 4 + r) * 64 + lane] = acc[bt][r];
+  __syncthreads();
+  for (int e = t; e < NBT * 4 * 64; e += 512) {
+    T s = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w * (NBT * 4 * 64) + e];
+    const int l = e & 63, r = (e >> 6) & 3, bt = e >> 8;
+    const long b = bt * 16 + Mfma<T>::row(l, r);
+    const long jo = j0 + (l & 15);
+    if (b < Bt && jo < n) out[b * n + jo] = s;
+  }
+}
+
 template <typename T>
 int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out, const int* gate) {
-  if (Bt > 8) {
+  if (Bt >= 2 && Bt <= 128) {
+    const int nbt = Bt <= 16 ? 1 : (Bt <= 32 ? 2 : (Bt <= 64 ? 4 : 8));
+    const int BP = 16 * nbt;
+    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)n * BP * sizeof(T)));
+    T* Pt = (T*)h->ws;
+    const long tot = n * BP;
+    hipLaunchKernelGGL((transpose_pad_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P,
+                       Bt, n, Pt, BP, gate);
+    MGP_LAUNCH_CHECK(h);
+    dim3 grid((unsigned)((n + 15) / 16));
+#define MGP_SK(NBTV) \
+  hipLaunchKernelGGL((symm_skinny_kernel<T, NBTV>), grid, dim3(512), 0, h->stream, A, n, (const T*)Pt, Bt, out, gate)
+    if (nbt == 1) MGP_SK(1);
+    else if (nbt == 2) MGP_SK(2);
+    else if (nbt == 4) MGP_SK(4);
+    else MGP_SK(8);
+#undef MGP_SK
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
+  }
+  if (Bt > 128) {
     dim3 grid((unsigned)((n + 127) / 128), (unsigned)((Bt + 127) / 128));
     hipLaunchKernelGGL((symm_gemm_kernel<T>), grid, dim3(256), 0, h->stream, A, n, P, Bt, out, gate);
     MGP_LAUNCH_CHECK(h);

@@ -27,10 +27,12 @@ struct mgp_handle {
   size_t opws_bytes = 0;
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
+  void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
   int num_cus = 256;
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
   int sweep_mode = 0;
+  int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;

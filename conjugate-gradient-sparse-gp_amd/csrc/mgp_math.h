@@ -81,6 +81,28 @@ MGP_HD double mgp_fma(double a, double b, double c) { return __builtin_fma(a, b,
 MGP_HD float mgp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 MGP_HD double mgp_sqrt(double x) { return __builtin_sqrt(x); }
+
+// sqrt for x known to be a positive normal number well inside the exponent range (the Matern
+// profiles clamp their argument to >= c^2 * 1e-36): v_rsq_f64 seed + Goldschmidt step + two
+// residual corrections, without the range scaling and special-case selects of the generic
+// lowering (10 instructions instead of ~17 in an fp64-VALU-bound loop).
+MGP_HD double mgp_sqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+MGP_HD float mgp_sqrt_pos(float x) { return __builtin_sqrtf(x); }
 MGP_HD float mgp_sqrt(float x) { return __builtin_sqrtf(x); }
 
 // Input scaling c_kind such that, with a = x*c/l and b = z*c/l,
@@ -120,7 +142,7 @@ MGP_HD T mgp_profile(T neg_s, T clamp, E2 e2 = E2()) {
   } else {
     T s = -neg_s;
     s = s > clamp ? s : clamp;
-    const T q = mgp_sqrt(s);
+    const T q = mgp_sqrt_pos(s);
     const T e = e2(-q);
     if (KIND == 1) return e;
     if (KIND == 2) return mgp_fma(q, (T)MGP_LN2, (T)1.0) * e;

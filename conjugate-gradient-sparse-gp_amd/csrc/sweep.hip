@@ -21,13 +21,14 @@ namespace {
 template <int DP>
 struct TileCfg {
   static constexpr int TB = DP <= 8 ? 256 : (DP <= 16 ? 128 : 64);  // broadcast points per LDS tile
-  static constexpr int RPT = DP <= 8 ? 4 : (DP <= 16 ? 2 : 1);      // owned points per lane
-  static constexpr int UJ = RPT >= 4 ? 1 : 2;                        // streamed points per loop trip
+  static constexpr int RPT = DP <= 8 ? 4 : 2;                        // owned points per lane
+  static constexpr int UJ = (RPT >= 4 || DP >= 32) ? 1 : 2;          // streamed points per loop trip
 };
 
 constexpr int kThreads = 256;
 
-template <typename T, int DP, int KIND, int RC>
+// SQ = true accumulates k^2 instead of k (diag of K_mn K_nm for the Jacobi preconditioner)
+template <typename T, int DP, int KIND, int RC, bool SQ = false>
 __global__ __launch_bounds__(kThreads) void sweep_kernel(
     const T* __restrict__ A, long na, const T* __restrict__ B, long nb, long b_chunk,
     const T* __restrict__ W, long w_sj, long w_sr, T* __restrict__ out, long o_si, long o_sr,
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
           T s = nb2 - a2[q];
 #pragma unroll
           for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
-          const T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
+          T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
+          if (SQ) kv = kv * kv;
 #pragma unroll
           for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
         }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
       body(E2Tab<true>{e2tab});
   }
 
-  const T var = (T)prm.variance;
+  const T var = SQ ? (T)(prm.variance * prm.variance) : (T)prm.variance;
   T* o = out + (long)by * o_chunk;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restri
   }
 }
 
-template <typename T, int DP, int KIND, int RC>
+template <typename T, int DP, int KIND, int RC, bool SQ = false>
 int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long na, const T* B, long nb,
                  const T* W, long w_sj, long w_sr, T* out, long o_si, long o_sr, T alpha, const T* addend,
                  long ad_si, long ad_sr, const int* gate) {
@@ -223,7 +225,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   // enough workgroups to fill the chip: none of the streamed set is split when the owned side
   // already gives >= 4 workgroups per CU, else aim for ~8 per CU
   const long target = 8L * h->num_cus;
-  long nchunks = nblk >= 4L * h->num_cus ? 1 : (target + nblk - 1) / nblk;
+  long nchunks = nblk >= (long)h->nosplit_per_cu * h->num_cus ? 1 : (target + nblk - 1) / nblk;
   const long max_chunks = (nb + TB - 1) / TB;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
@@ -235,7 +237,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   dim3 grid((unsigned)(nblk * nchunks));
   if (nchunks == 1) {
     hipEvent_t stop = mgp_prof_begin(h);
-    hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
+    hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC, SQ>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                        b_chunk, W, w_sj, w_sr, out, o_si, o_sr, 0L, D, prm, alpha, addend, ad_si, ad_sr, gate, (int)nblk,
                        (int)nchunks);
     mgp_prof_end(h, stop);
@@ -246,7 +248,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, need));
   T* part = (T*)h->ws;
   hipEvent_t stop = mgp_prof_begin(h);
-  hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
+  hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC, SQ>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                      b_chunk, W, w_sj, w_sr, part, 1L, na, na * (long)RC, D, prm, (T)0, (const T*)nullptr, 0L,
                      0L, gate, (int)nblk, (int)nchunks);
   mgp_prof_end(h, stop);
@@ -289,6 +291,31 @@ int sweep_rc(mgp_handle* h, const SweepParams& prm, int D, const T* A, long na, 
     r0 += rc;
   }
   return MGP_OK;
+}
+
+template <typename T, int KIND>
+int sweep_sq_dp(mgp_handle* h, const SweepParams& prm, int D, const T* A, long na, const T* B, long nb, const T* one,
+                T* out) {
+#define MGP_SQ_CASE(DPV)                                                                                      \
+  return launch_sweep<T, DPV, KIND, 1, true>(h, prm, D, A, na, B, nb, one, 0L, 0L, out, 1L, na, (T)0, nullptr, 0L, \
+                                             0L, nullptr)
+  if (D <= 2) MGP_SQ_CASE(2);
+  if (D <= 4) MGP_SQ_CASE(4);
+  if (D <= 8) MGP_SQ_CASE(8);
+  if (D <= 16) MGP_SQ_CASE(16);
+  MGP_SQ_CASE(32);
+#undef MGP_SQ_CASE
+}
+
+template <typename T>
+int sweep_sq_kind(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* B, long nb, const T* one, T* out) {
+  const SweepParams prm = mgp_make_params(k);
+  switch (k->kind) {
+    case MGP_SE: return sweep_sq_dp<T, 0>(h, prm, k->D, A, na, B, nb, one, out);
+    case MGP_MATERN12: return sweep_sq_dp<T, 1>(h, prm, k->D, A, na, B, nb, one, out);
+    case MGP_MATERN32: return sweep_sq_dp<T, 2>(h, prm, k->D, A, na, B, nb, one, out);
+    default: return sweep_sq_dp<T, 3>(h, prm, k->D, A, na, B, nb, one, out);
+  }
 }
 
 template <typename T, int KIND>
@@ -350,6 +377,24 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
   return sweep_kind<float>(h, k, (const float*)A, na, (const float*)B, nb, (const float*)W.base, W.si, W.sr, R,
                            (float*)out.base, out.si, out.sr, (float)alpha, (const float*)addend.base, addend.si,
                            addend.sr, gate);
+}
+
+// out[m] = sum_i k(x_i, z_m)^2 = diag(K_mn K_nm)
+extern "C" int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                                 int64_t M, void* out) {
+  MGP_TRY(mgp_check_kernel(h, k));
+  if (N < 0 || M < 0) return mgp_fail(h, MGP_E_SHAPE, "negative size");
+  if (M == 0) return MGP_OK;
+  if (!Z || !out || (N > 0 && !X)) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (N == 0) {
+    MGP_HIP(h, hipMemsetAsync(out, 0, (size_t)M * mgp_elem(k->dtype), h->stream));
+    return MGP_OK;
+  }
+  if (k->dtype == MGP_F64)
+    return sweep_sq_kind<double>(h, k, (const double*)Z, M, (const double*)X, N, (const double*)h->ones,
+                                 (double*)out);
+  return sweep_sq_kind<float>(h, k, (const float*)Z, M, (const float*)X, N, (const float*)((char*)h->ones + 8),
+                              (float*)out);
 }
 
 extern "C" int mgp_knm_matvec(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,

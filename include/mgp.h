@@ -136,6 +136,11 @@ int mgp_k_dense(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, c
 int mgp_kmn_knm(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
                 int64_t M, void* out);
 
+/* out[M] = sum_i k(x_i, z_m)^2 = diag(K_mn K_nm): the N-sized part of diag(S) for the Jacobi
+ * preconditioner of the SGPR normal equations (build-side addition, no reference counterpart). */
+int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                      int64_t M, void* out);
+
 /* ---- dense symmetric product (row M2: `state.p @ A`, conjugate_gradient.py:65) ---------
  * out[Bt,n] = P[Bt,n] @ A[n,n] for SYMMETRIC A (CG requires it; computed as rows of A dotted
  * with p_b, i.e. P @ A^T). */
