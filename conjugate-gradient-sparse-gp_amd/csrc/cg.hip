@@ -23,6 +23,8 @@ namespace {
 struct CgCtrl {
   int active;
   int iters;
+  unsigned ticket;  // arrivals of the fused update kernel's workgroups (reset by the last one)
+  int pad;
 };
 
 template <typename T>
@@ -146,6 +148,108 @@ __global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict
     rz[blockIdx.x] = s_rz;
     err[blockIdx.x] = (T)0.5 * s_rz;
     over[blockIdx.x] = ((T)0.5 * s_rr > thr) ? 1 : 0;
+  }
+}
+
+// Fused common-case step (no refresh, Eye or Jacobi): the whole update of one RHS with its
+// elements held in registers (EPT per thread), two block reductions instead of four, and the
+// iteration bookkeeping (`any` over the RHS flags, step counter, next gate) done by the last
+// workgroup to arrive -- agent-scope fence + ticket, no extra launch.
+template <typename T, int EPT, int NT>
+__global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict__ ctrl, T* __restrict__ v,
+                                                             T* __restrict__ r, T* __restrict__ p,
+                                                             const T* __restrict__ ap, T* __restrict__ rz,
+                                                             int* __restrict__ over, T* __restrict__ err, long n,
+                                                             T thr, T min_float, const T* __restrict__ dinv,
+                                                             int max_it) {
+  if (ctrl->active == 0) return;
+  __shared__ T red[2][NT / 64];
+  __shared__ int last_flag;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long off = (long)blockIdx.x * n;
+  const T rz_old = rz[blockIdx.x];
+  T pv[EPT], av[EPT], rv[EPT];
+  T d = 0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const long j = (long)e * NT + t;
+    const bool ok = j < n;
+    pv[e] = ok ? p[off + j] : (T)0;
+    av[e] = ok ? ap[off + j] : (T)0;
+    rv[e] = ok ? r[off + j] : (T)0;
+    d = mgp_fma(pv[e], av[e], d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if (lane == 0) red[0][wave] = d;
+  __syncthreads();
+  d = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) d += red[0][w];
+  const T gamma = (d <= min_float) ? (T)0 : rz_old / d;
+  T s_rz = 0, s_rr = 0;
+  T zv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const long j = (long)e * NT + t;
+    if (j < n) v[off + j] = mgp_fma(gamma, pv[e], v[off + j]);
+    rv[e] = mgp_fma(-gamma, av[e], rv[e]);
+    zv[e] = dinv != nullptr ? (j < n ? rv[e] * dinv[j] : (T)0) : rv[e];
+    s_rz = mgp_fma(zv[e], rv[e], s_rz);
+    s_rr = mgp_fma(rv[e], rv[e], s_rr);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s_rz += __shfl_xor(s_rz, o, 64);
+    s_rr += __shfl_xor(s_rr, o, 64);
+  }
+  __syncthreads();  // red[0] fully read
+  if (lane == 0) {
+    red[0][wave] = s_rz;
+    red[1][wave] = s_rr;
+  }
+  __syncthreads();
+  s_rz = 0;
+  s_rr = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    s_rz += red[0][w];
+    s_rr += red[1][w];
+  }
+  const T beta = (rz_old <= min_float) ? (T)0 : s_rz / rz_old;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const long j = (long)e * NT + t;
+    if (j < n) {
+      r[off + j] = rv[e];
+      p[off + j] = mgp_fma(beta, pv[e], zv[e]);
+    }
+  }
+  if (t == 0) {
+    rz[blockIdx.x] = s_rz;
+    err[blockIdx.x] = (T)0.5 * s_rz;
+    __hip_atomic_store(&over[blockIdx.x], ((T)0.5 * s_rr > thr) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();  // release: this workgroup's flag is visible before its ticket
+    const unsigned tk = atomicAdd(&ctrl->ticket, 1u);
+    last_flag = (tk == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last_flag) {  // last workgroup to arrive: every flag has been published
+    __shared__ int any;
+    if (t == 0) any = 0;
+    __threadfence();  // acquire
+    __syncthreads();
+    int a = 0;
+    for (long b = t; b < (long)gridDim.x; b += NT)
+      a |= __hip_atomic_load(&over[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a) atomicOr(&any, 1);
+    __syncthreads();
+    if (t == 0) {
+      const int it = ctrl->iters + 1;
+      ctrl->iters = it;
+      ctrl->ticket = 0;
+      ctrl->active = (any && it < max_it) ? 1 : 0;
+    }
   }
 }
 
@@ -311,6 +415,17 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 0, (int)max_it);
   MGP_LAUNCH_CHECK(h);
 
+  // fused step kernel: elements of one RHS in registers.  Code = EPT for 256 threads (n <= 1024),
+  // 14/12/24/8 for 1024 threads with EPT 1/2/4/8 (n <= 8192); 0 = generic loop kernels.
+  int fused_ept = 0;
+  if (pc.kind != MGP_PRE_BLOCK && Bt < 2147483647L) {
+    if (n <= 256) fused_ept = 1;
+    else if (n <= 512) fused_ept = 2;
+    else if (n <= 1024) fused_ept = 14;
+    else if (n <= 2048) fused_ept = 12;
+    else if (n <= 4096) fused_ept = 24;
+    else if (n <= 8192) fused_ept = 8;
+  }
   if (check_every < 1) check_every = 1;
   long enq = 0;  // iterations enqueued so far (index of the next one)
   CgCtrl host{1, 0};
@@ -324,7 +439,24 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     for (long q = 0; q < batch; ++q, ++enq) {
       const bool reset = (enq % cycle) == (cycle - 1);  // :71 (enq == state.i while active)
       MGP_TRY(apply_operator<T>(h, op, p, Bt, ap, &ctrl->active));
-      if (!reset) {
+      if (!reset && fused_ept > 0) {
+        const T* dinv = pc.kind == MGP_PRE_JACOBI ? (const T*)pc.diag_inv : nullptr;
+#define MGP_FUSED(EPTV, NTV)                                                                                   \
+  hipLaunchKernelGGL((cg_update_fused_kernel<T, EPTV, NTV>), dim3((unsigned)Bt), dim3(NTV), 0, s, ctrl, V, r, p, ap, \
+                     rz, over, err_out, n, (T)thr, (T)min_float, dinv, (int)max_it)
+        switch (fused_ept) {
+          case 1: MGP_FUSED(1, 256); break;
+          case 2: MGP_FUSED(2, 256); break;
+          case 4: MGP_FUSED(4, 256); break;
+          case 14: MGP_FUSED(1, 1024); break;
+          case 12: MGP_FUSED(2, 1024); break;
+          case 24: MGP_FUSED(4, 1024); break;
+          default: MGP_FUSED(8, 1024); break;
+        }
+#undef MGP_FUSED
+        MGP_LAUNCH_CHECK(h);
+        continue;  // bookkeeping done inside the kernel
+      } else if (!reset) {
         hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, 0);
       } else {
