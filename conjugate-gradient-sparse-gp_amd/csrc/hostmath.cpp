@@ -20,6 +20,20 @@ void mgp_host_profile(int kind, const double* s, double* out, long n) {
   }
 }
 double mgp_host_profile_scale(int kind) { return mgp_profile_scale(kind); }
+// out[i] = 2^(s[i] - a2[i]) through the shifted table form, including the per-point 2^rho
+void mgp_host_exp2_shifted(const double* s, const double* a2, double* out, long n) {
+  static double tab[MGP_EXP2_TAB_SIZE];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < MGP_EXP2_TAB_SIZE; ++i) tab[i] = mgp_exp2_tab_entry(i);
+    init = true;
+  }
+  for (long i = 0; i < n; ++i) {
+    const volatile double Cq = MGP_EXP2_MAGIC - a2[i];
+    const double rho = (MGP_EXP2_MAGIC - Cq) - a2[i];
+    out[i] = mgp_exp2(rho) * mgp_exp2_tab_shifted(s[i], Cq, tab);
+  }
+}
 void mgp_host_exp2_tab(const double* t, double* out, long n) {
   static double tab[MGP_EXP2_TAB_SIZE];
   static bool init = false;

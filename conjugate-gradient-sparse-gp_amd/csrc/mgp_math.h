@@ -69,6 +69,26 @@ MGP_HD double mgp_exp2_tab(double t, const double* tab) {
   return __builtin_ldexp(__builtin_fma(T, q, T), m >> MGP_EXP2_TAB_BITS);
 }
 
+// Shifted form for the SE sweep: the exponent is t = s - a2 with a2 constant per owned point.
+// Folding a2 into the magic constant saves the subtraction: Cq = fl(1.5*2^41 - a2) (a multiple
+// of 2^-11), u = s + Cq, and with rho = (1.5*2^41 - Cq) - a2 (|rho| <= 2^-12, per owned point)
+//     2^(s - a2) = 2^rho * ldexp(T[m & 2047] * 2^g, m >> 11),   g = s - (u - Cq)  (exact),
+// m = low word of u.  The caller multiplies the accumulated sum by 2^rho once per owned point.
+// Only legal when |s - a2| < 2^19 (same bound as the unclamped table form).
+MGP_HD double mgp_exp2_tab_shifted(double s, double Cq, const double* tab) {
+  const double u = s + Cq;
+  long long bits;
+  __builtin_memcpy(&bits, &u, sizeof(bits));
+  const int m = (int)bits;
+  const double g = s - (u - Cq);
+  double q = __builtin_fma(g, 0x1.c6b08d704a0c0p-5, 0x1.ebfbdff82c58fp-3);
+  q = __builtin_fma(q, g, 0x1.62e42fefa39efp-1);
+  q = q * g;
+  const double T = tab[m & (MGP_EXP2_TAB_SIZE - 1)];
+  return __builtin_ldexp(__builtin_fma(T, q, T), m >> MGP_EXP2_TAB_BITS);
+}
+#define MGP_EXP2_MAGIC 0x1.8p+41
+
 MGP_HD float mgp_exp2(float t) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_exp2f(t);  // v_exp_f32, 1 ulp

@@ -29,7 +29,7 @@ constexpr int kThreads = 256;
 
 // SQ = true accumulates k^2 instead of k (diag of K_mn K_nm for the Jacobi preconditioner)
 template <typename T, int DP, int KIND, int RC, bool SQ = false>
-__global__ __launch_bounds__(kThreads) void sweep_kernel(
+__global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_kernel(
     const T* __restrict__ A, long na, const T* __restrict__ B, long nb, long b_chunk,
     const T* __restrict__ W, long w_sj, long w_sr, T* __restrict__ out, long o_si, long o_sr,
     long o_chunk, int D, SweepParams prm, T alpha, const T* __restrict__ addend, long ad_si,
@@ -66,10 +66,23 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
   __shared__ T bmax_w[kThreads / 64];  // per-wave max |b|^2 of the staged tile
   __shared__ T amax_w[kThreads / 64];
 
+  // SE / fp64 fast path: a2 is folded into the exp2 magic constant (mgp_exp2_tab_shifted)
+  constexpr bool FAST = KIND == 0 && sizeof(T) == 8 && !SQ;
+
   // ---- owned points: scaled coordinates and squared norm in registers
+  // (FAST keeps only cq per owned point live across the sweep; a2 and the 2^rho scales are
+  // recomputed from the coordinates where the rare paths need them -- register pressure decides
+  // between 3 and 4 waves per SIMD here)
   T a[RPT][DP];
-  T a2[RPT];
+  T a2[FAST ? 1 : RPT];
+  double cq[FAST ? RPT : 1];
   T acc[RPT][RC];
+  auto norm2 = [&](int q) {
+    T s = 0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], a[q][d], s);
+    return s;
+  };
   T amax = 0;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -82,8 +95,11 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
       a[q][d] = v;
       s = mgp_fma(v, v, s);
     }
-    a2[q] = s;
     amax = s > amax ? s : amax;
+    if (FAST)
+      cq[q] = (double)MGP_EXP2_MAGIC - (double)s;  // rounded to a multiple of 2^-11
+    else
+      a2[q] = s;
 #pragma unroll
     for (int r = 0; r < RC; ++r) acc[q][r] = 0;
   }
@@ -138,6 +154,13 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
     const bool safe = (T)2 * (aa + bb) < (T)524288;  // NaN inputs compare false -> clamped loop
 
     auto body = [&](auto e2) {
+      T a2l[RPT];
+      double fb[RPT];  // FAST: 2^(-rho) so that the common 2^rho epilogue stays valid
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        a2l[q] = FAST ? norm2(q) : a2[FAST ? 0 : q];
+        fb[q] = FAST ? mgp_exp2(-(((double)MGP_EXP2_MAGIC - cq[FAST ? q : 0]) - (double)a2l[q])) : 1.0;
+      }
 #pragma unroll UJ
       for (int jj = 0; jj < TB; ++jj) {
         const T* p = &tile[jj * PS];
@@ -150,20 +173,47 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
         for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-          T s = nb2 - a2[q];
+          T s = nb2 - a2l[q];
 #pragma unroll
           for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
           T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
           if (SQ) kv = kv * kv;
+          if (FAST) kv = (T)((double)kv * fb[q]);
 #pragma unroll
           for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
         }
       }
     };
-    if (safe)
-      body(E2Tab<false>{e2tab});
-    else
+    auto body_fast = [&]() {
+#pragma unroll UJ
+      for (int jj = 0; jj < TB; ++jj) {
+        const T* p = &tile[jj * PS];
+        T b[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) b[d] = p[d];
+        const T nb2 = p[DP];
+        T w[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          T s = nb2;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
+          const T kv = (T)mgp_exp2_tab_shifted((double)s, cq[FAST ? q : 0], e2tab);
+#pragma unroll
+          for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
+        }
+      }
+    };
+    if (safe) {
+      if (FAST)
+        body_fast();
+      else
+        body(E2Tab<false>{e2tab});
+    } else {
       body(E2Tab<true>{e2tab});
+    }
   }
 
   const T var = SQ ? (T)(prm.variance * prm.variance) : (T)prm.variance;
@@ -175,6 +225,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
         T v = var * acc[q][r];
+        if (FAST) v = (T)((double)v * mgp_exp2(((double)MGP_EXP2_MAGIC - cq[q]) - (double)norm2(q)));  // 2^rho
         if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si + r * ad_sr], v);
         o[i * o_si + r * o_sr] = v;
       }

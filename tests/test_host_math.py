@@ -21,6 +21,7 @@ def hm():
     lib = ctypes.CDLL(SO)
     for n in ("mgp_host_exp2", "mgp_host_exp2_tab"):
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    lib.mgp_host_exp2_shifted.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long]
     lib.mgp_host_profile.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
     lib.mgp_host_profile_scale.restype = ctypes.c_double
     return lib
@@ -56,3 +57,16 @@ def test_profiles_match_gpflow_formulas(hm, kind, name):
     ref = Kernel(name).K_r2(r2)
     assert np.max(np.abs(out - ref) / ref) < 2e-14
     assert out[-3] == 1.0 and abs(out[-2] - 1.0) < 1e-15
+
+
+def test_shifted_table_form_of_the_se_sweep(hm):
+    """2^(s - a2) with a2 folded into the magic constant (the SE fast path of csrc/sweep.hip)."""
+    rng = np.random.default_rng(0)
+    n = 300000
+    a2 = rng.random(n) * rng.choice([1, 10, 1000, 2e5], n)
+    s = -rng.random(n) * rng.choice([1, 60, 1000], n) + a2
+    out = np.empty(n)
+    hm.mgp_host_exp2_shifted(s.ctypes.data, a2.ctypes.data, out.ctypes.data, n)
+    ref = np.exp2(s.astype(np.longdouble) - a2.astype(np.longdouble)).astype(np.float64)
+    m = ref > 1e-300
+    assert np.max(np.abs(out[m] / ref[m] - 1)) <= 5e-16
