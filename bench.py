@@ -78,7 +78,8 @@ def main():
         variance=syn.variance, lengthscales=syn.lengthscales)
     spec = kern.spec(D)
     allreduce = parallel.make_allreduce()
-    op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1)
+    op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1,
+                            kmm_rows=parallel.kmm_slab(M))
     rhs = ops.kmn_matvec(spec, X, Z, y)  # K_mn y  [M,1]
     if allreduce is not None:
         allreduce(rhs.view(-1))

@@ -57,6 +57,8 @@ class MgpOperator(ctypes.Structure):
         ("allreduce", ALLREDUCE_FN),
         ("allreduce_ctx", ctypes.c_void_p),
         ("partial_buf", ctypes.c_void_p),
+        ("kmm_row_begin", ctypes.c_int64),
+        ("kmm_row_end", ctypes.c_int64),
     ]
 
 

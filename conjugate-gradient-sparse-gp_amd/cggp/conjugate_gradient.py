@@ -130,7 +130,7 @@ class SgprNormalOperator(LinearOperator):
     summed over ranks once per application; Kmm, Z and the CG state are replicated.
     """
 
-    def __init__(self, kernel, X, Z, noise_variance, jitter=0.0, allreduce=None, max_rhs=1):
+    def __init__(self, kernel, X, Z, noise_variance, jitter=0.0, allreduce=None, max_rhs=1, kmm_rows=None):
         self.X = _hip.check_tensor(X, "X")
         self.Z = _hip.check_tensor(Z, "Z", dtype=self.X.dtype)
         if self.X.dim() != 2 or self.Z.dim() != 2 or self.X.shape[1] != self.Z.shape[1]:
@@ -144,6 +144,9 @@ class SgprNormalOperator(LinearOperator):
         self.dtype = self.Z.dtype
         self.device = self.Z.device
         self.allreduce = allreduce
+        # rows of Kmm whose s2*Kmm.p term this rank contributes before the all-reduce
+        # (parallel.kmm_slab(M)); the slabs of all ranks must tile [0, M)
+        self.kmm_rows = kmm_rows if allreduce is not None else None
         self._partial = None
         self._cb = None
         if allreduce is not None:
@@ -185,6 +188,11 @@ class SgprNormalOperator(LinearOperator):
         if self.allreduce is not None:
             st.allreduce = self._cb
             st.partial_buf = self._partial.data_ptr()
+            if self.kmm_rows is not None:
+                st.kmm_row_begin, st.kmm_row_end = int(self.kmm_rows[0]), int(self.kmm_rows[1])
+            else:  # no slab given: rank 0 alone adds the replicated term
+                import torch.distributed as dist
+                st.kmm_row_begin, st.kmm_row_end = (0, self.shape[0]) if dist.get_rank() == 0 else (0, -1)
         return st, (k, self.X, self.Z, self.Kmm, self._partial, self._cb)
 
     def rmatmul(self, P):

@@ -48,3 +48,13 @@ def make_allreduce(group=None):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return _allreduce
+
+
+def kmm_slab(M, world_size=None, rank=None):
+    """Row slab [lo, hi) of the replicated Kmm whose s2*Kmm.p term this rank adds to its partial of
+    the SGPR operator before the all-reduce (the slabs tile [0, M), so the sum is the full term)."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return shard_bounds(M, world_size, rank)

@@ -287,6 +287,17 @@ __global__ __launch_bounds__(256) void axpby_kernel(const int* __restrict__ gate
   if (i < total) out[i] = a * x[i] + b * y[i];
 }
 
+// t[b, j] += a * x[b, j] for the columns j in [rb, re)
+template <typename T>
+__global__ __launch_bounds__(256) void add_rows_slab_kernel(const int* __restrict__ gate, T a, const T* __restrict__ x,
+                                                            T* __restrict__ t, long n, long total, long rb, long re) {
+  if (gate != nullptr && *gate == 0) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long j = i % n;
+  if (j >= rb && j < re) t[i] = mgp_fma(a, x[i], t[i]);
+}
+
 // out[b, j] += lam[j] * p[b, j]
 template <typename T>
 __global__ __launch_bounds__(256) void add_diag_prod_kernel(const int* __restrict__ gate, const T* __restrict__ lam,
@@ -315,12 +326,15 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       return MGP_OK;
     }
     case MGP_OP_SGPR: {
-      // u[Bt, N] = (K_nm p^T)^T ; t[Bt, M] = (K_mn u^T)^T ; all-reduce t ; out = s2 * p @ Kmm + t
+      // u[Bt,N] = (K_nm p^T)^T ; t[Bt,M] = (K_mn u^T)^T over the local rows ; the replicated
+      // s2*Kmm.p term is added as this rank's row slab of it, so ONE all-reduce of t finishes S.p
       const long N = op->N, M = op->M;
-      const size_t need = ((size_t)Bt * N + (size_t)Bt * M) * sizeof(T);
+      // operator arena: u [Bt,N] | partial [Bt,M] | Kmm.p [Bt,M] (only for Bt > 1)
+      const size_t need = ((size_t)Bt * N + 2 * (size_t)Bt * M) * sizeof(T);
       MGP_TRY(mgp_reserve(h, &h->opws, &h->opws_bytes, need));
       T* u = (T*)h->opws;
-      T* tt = op->partial_buf ? (T*)op->partial_buf : u + Bt * N;
+      // the collective works on the caller's buffer when one is given; single rank: straight into out
+      T* tt = op->allreduce ? (op->partial_buf ? (T*)op->partial_buf : u + Bt * N) : out;
       if (N > 0) {
         MGP_TRY(mgp_sweep(h, op->kernel, op->X, N, op->Z, M, VecView{P, 1, M}, (int)Bt, VecViewMut{u, 1, N}, 0.0,
                           VecView{nullptr, 0, 0}, gate));
@@ -329,14 +343,23 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       } else {
         MGP_HIP(h, hipMemsetAsync(tt, 0, (size_t)Bt * M * sizeof(T), h->stream));
       }
-      MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, op->Kmm, M, P, Bt, out, gate));
+      long rb = op->kmm_row_begin, re = op->kmm_row_end;
+      if (rb == 0 && re == 0) re = M;  // unset: this rank owns every row of Kmm
+      if (Bt == 1) {
+        MGP_TRY(mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, op->s2, tt, gate));
+      } else {
+        // several RHS: full replicated product, then only this rank's slab of it is added
+        T* kmp = u + Bt * N + Bt * M;
+        MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, op->Kmm, M, P, Bt, kmp, gate));
+        hipLaunchKernelGGL((add_rows_slab_kernel<T>), dim3(nblk(Bt * M)), dim3(256), 0, h->stream, gate, (T)op->s2,
+                           (const T*)kmp, tt, M, Bt * M, rb, re);
+        MGP_LAUNCH_CHECK(h);
+      }
       if (op->allreduce) {
         const int rc = op->allreduce(op->allreduce_ctx, tt, (size_t)(Bt * M), op->dtype, (void*)h->stream);
         if (rc != 0) return mgp_fail(h, MGP_E_COMM, "allreduce callback returned %d", rc);
+        MGP_HIP(h, hipMemcpyAsync(out, tt, (size_t)Bt * M * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
       }
-      hipLaunchKernelGGL((axpby_kernel<T>), dim3(nblk(Bt * M)), dim3(256), 0, h->stream, gate, (T)op->s2,
-                         (const T*)out, (T)1, (const T*)tt, out, Bt * M);
-      MGP_LAUNCH_CHECK(h);
       return MGP_OK;
     }
     default:

@@ -108,18 +108,19 @@ __device__ __forceinline__ T wave_sum(T v) {
 template <typename T, int BT, int VEC>
 __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A, long n,
                                                         const T* __restrict__ P, int bt, T* __restrict__ out,
-                                                        const int* __restrict__ gate) {
+                                                        const int* __restrict__ gate, long row_begin, long row_end,
+                                                        T alpha, int accumulate) {
   if (gate != nullptr && *gate == 0) return;
   constexpr int RW = 2;
   const int lane = threadIdx.x & 63;
-  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
-  if (row0 >= n) return;
+  const long row0 = row_begin + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= row_end) return;
   T acc[RW][BT];
 #pragma unroll
   for (int q = 0; q < RW; ++q)
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[q][b] = 0;
-  const long r1 = row0 + 1 < n ? row0 + 1 : row0;
+  const long r1 = row0 + 1 < row_end ? row0 + 1 : row0;
   const T* a0 = A + row0 * n;
   const T* a1 = A + r1 * n;
   for (long i = (long)lane * VEC; i < n; i += 64 * VEC) {
@@ -155,7 +156,10 @@ __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A,
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       const T s = wave_sum(acc[q][b]);
-      if (lane == 0 && b < bt && row0 + q < n) out[(long)b * n + row0 + q] = s;
+      if (lane == 0 && b < bt && row0 + q < row_end) {
+        T* o = &out[(long)b * n + row0 + q];
+        *o = accumulate ? mgp_fma(alpha, s, *o) : s;
+      }
     }
 }
 
@@ -365,10 +369,10 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
   do {                                                                                                          \
     if (vec)                                                                                                    \
       hipLaunchKernelGGL((symm_gemv_kernel<T, BTV, VECW>), grid, dim3(256), 0, h->stream, A, n, P, (int)Bt, out, \
-                         gate);                                                                                 \
+                         gate, 0L, n, (T)1, 0);                                                                 \
     else                                                                                                        \
       hipLaunchKernelGGL((symm_gemv_kernel<T, BTV, 1>), grid, dim3(256), 0, h->stream, A, n, P, (int)Bt, out,    \
-                         gate);                                                                                 \
+                         gate, 0L, n, (T)1, 0);                                                                 \
   } while (0)
   if (Bt == 1) MGP_GV(1);
   else if (Bt == 2) MGP_GV(2);
@@ -380,6 +384,32 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
 }
 
 }  // namespace
+
+// out[row] += alpha * A[row,:].p for rows [row_begin,row_end) (one RHS): a rank's slab of the
+// replicated s2*Kmm.p term of the SGPR operator, added into its partial before the all-reduce
+template <typename T>
+int symm_gemv_rows_t(mgp_handle* h, const T* A, long n, const T* p, long rb, long re, T alpha, T* out,
+                     const int* gate) {
+  if (re <= rb) return MGP_OK;
+  constexpr int VECW = 16 / sizeof(T);
+  const bool vec = (n % VECW) == 0 && (((uintptr_t)A) % 16) == 0;
+  dim3 grid((unsigned)((re - rb + 7) / 8));
+  if (vec)
+    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, VECW>), grid, dim3(256), 0, h->stream, A, n, p, 1, out, gate, rb, re,
+                       alpha, 1);
+  else
+    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, 1>), grid, dim3(256), 0, h->stream, A, n, p, 1, out, gate, rb, re,
+                       alpha, 1);
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
+                           double alpha, void* out, const int* gate) {
+  if (dtype == MGP_F64)
+    return symm_gemv_rows_t<double>(h, (const double*)A, n, (const double*)p, rb, re, alpha, (double*)out, gate);
+  return symm_gemv_rows_t<float>(h, (const float*)A, n, (const float*)p, rb, re, (float)alpha, (float*)out, gate);
+}
 
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
                           void* out, const int* gate) {

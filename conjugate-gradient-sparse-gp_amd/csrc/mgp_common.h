@@ -150,5 +150,7 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
 int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long na, const double* B, long nb,
                        const double* W, long w_sj, long w_sr, int R, double* out, long o_si, long o_sr,
                        double alpha, const double* addend, long ad_si, long ad_sr, const int* gate);
+int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
+                           double alpha, void* out, const int* gate);
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
                           void* out, const int* gate);

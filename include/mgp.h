@@ -92,6 +92,9 @@ typedef struct {
    * K_mn(K_nm p) before the collective (so a host-side collective can address it as its own
    * tensor); NULL = library scratch. */
   void* partial_buf;
+  /* MGP_OP_SGPR, multi-rank: rows [kmm_row_begin, kmm_row_end) of Kmm whose s2*Kmm.p contribution
+   * THIS rank adds to its partial (the slabs of all ranks must tile [0,M)); 0,0 = all rows. */
+  int64_t kmm_row_begin, kmm_row_end;
 } mgp_operator;
 
 typedef struct {

@@ -109,7 +109,13 @@ def _gpu_worker(rank, world, port, out):
     kern = kernels.Matern32(1.2, [0.8, 1.0, 1.3])
     Xl = parallel.shard_rows(torch.from_numpy(X)).to(dev)
     Zt = torch.from_numpy(Z).to(dev)
-    op = SgprNormalOperator(kern, Xl, Zt, 0.1, jitter=1e-6, allreduce=parallel.make_allreduce())
+    # rank 0 shards the replicated s2*Kmm.p term too; a second operator leaves it on rank 0
+    op = SgprNormalOperator(kern, Xl, Zt, 0.1, jitter=1e-6, allreduce=parallel.make_allreduce(),
+                            kmm_rows=parallel.kmm_slab(40))
+    op_r0 = SgprNormalOperator(kern, Xl, Zt, 0.1, jitter=1e-6, allreduce=parallel.make_allreduce())
+    v1 = torch.from_numpy(V[:, :1].copy()).to(dev)
+    same = float((op.matmul(v1) - op_r0.matmul(v1)).abs().max()) / float(op.matmul(v1).abs().max())
+    assert same < 1e-13, same
     Sv = op.matmul(torch.from_numpy(V).to(dev))
     rhs = torch.from_numpy(np.random.default_rng(1).standard_normal((40, 3))).to(dev)
     sol, (steps, err) = ConjugateGradient(1e-12, max_iterations=3000).solve_with_stats(op, rhs)
