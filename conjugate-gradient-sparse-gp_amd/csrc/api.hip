@@ -20,6 +20,10 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
   const char* mode = getenv("MGP_SWEEP");
   if (mode && strcmp(mode, "mfma") == 0) h->sweep_mode = 1;
+  const char* pm = getenv("MGP_CONTRACT_PANEL_MB");
+  if (pm && atoi(pm) > 0) h->contract_panel_mb = (size_t)atoi(pm);
+  const char* nz = getenv("MGP_CONTRACT_NZ");
+  if (nz && atoi(nz) > 0 && atoi(nz) <= 64) h->contract_nz = atoi(nz);
   const char* ns = getenv("MGP_NOSPLIT_PER_CU");
   if (ns && atoi(ns) > 0) h->nosplit_per_cu = atoi(ns);
   if (hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault) != hipSuccess) {

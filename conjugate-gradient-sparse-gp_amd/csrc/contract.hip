@@ -8,6 +8,8 @@
 // partial tiles are summed in fixed order by a second kernel, which also mirrors the lower
 // triangle (deterministic, no float atomics).  2 N M^2 flop on the matrix cores (half of it
 // skipped by symmetry) next to N M (D + profile) VALU work per tile column.
+#include <cstdlib>
+
 #include "mgp_common.h"
 
 namespace {
@@ -214,6 +216,55 @@ int kmn_knm_t(mgp_handle* h, const mgp_kernel* k, const T* X, long N, const T* Z
 
 }  // namespace
 
+// Two-stage form (default): per chunk of rows, materialise K^T = k(Z, X_chunk) [M, rows] once
+// (N*M kernel evaluations in total instead of ~33x that in the fused tiles) and accumulate
+// K^T K^T^T on upper-triangular 128x128 tiles with the NT MFMA GEMM of dense.hip; chunks are
+// accumulated in order (deterministic), the lower triangle is mirrored at the end.
+static int kmn_knm_two_stage(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
+                             int64_t M, void* out) {
+  const size_t es = mgp_elem(k->dtype);
+  // 528 upper tiles on 512 resident workgroups would leave a full-length tail round, so every
+  // launch contracts NZ independent column slices of the panel (grid.z) into NZ accumulators.
+  const int NZ = h->contract_nz;
+  int64_t rows = (int64_t)((h->contract_panel_mb << 20) / ((size_t)M * es));  // panel columns per launch
+  rows = rows / (16 * NZ) * (16 * NZ);
+  if (rows < 16 * NZ) rows = 16 * NZ;
+  const size_t panel = (size_t)M * rows * es, slices = (size_t)NZ * M * M * es;
+  const int nt = (int)((M + 127) / 128), ntiles = nt * (nt + 1) / 2;
+  const size_t tab_bytes = (size_t)ntiles * 2 * sizeof(int);
+  MGP_TRY(mgp_reserve(h, &h->opws, &h->opws_bytes, panel + slices + tab_bytes + 256));
+  char* Kt = (char*)h->opws;
+  char* acc = Kt + panel;
+  int* tab_dev = (int*)(acc + ((slices + 255) & ~(size_t)255));
+  {
+    std::string tab;
+    tab.resize(tab_bytes);
+    int* tp = (int*)&tab[0];
+    int e = 0;
+    for (int a = 0; a < nt; ++a)
+      for (int b = a; b < nt; ++b) {
+        tp[2 * e] = a;
+        tp[2 * e + 1] = b;
+        ++e;
+      }
+    MGP_HIP(h, hipMemcpyAsync(tab_dev, tp, tab_bytes, hipMemcpyHostToDevice, h->stream));
+    MGP_HIP(h, hipStreamSynchronize(h->stream));  // tab is a host temporary
+  }
+  MGP_HIP(h, hipMemsetAsync(acc, 0, slices, h->stream));
+  for (int64_t i0 = 0; i0 < N; i0 += rows) {
+    const int64_t rc = (N - i0 < rows) ? N - i0 : rows;
+    const char* Xc = (const char*)X + (size_t)i0 * k->D * es;
+    if (rc == rows) {
+      MGP_TRY(mgp_k_dense(h, k, Z, M, Xc, rc, Kt, rc, 0.0, nullptr));
+      MGP_TRY(mgp_syrk_nt_upper(h, k->dtype, Kt, M, rc / NZ, rc, acc, 1, NZ, tab_dev, ntiles));
+    } else {  // ragged tail: one slice
+      MGP_TRY(mgp_k_dense(h, k, Z, M, Xc, rc, Kt, rc, 0.0, nullptr));
+      MGP_TRY(mgp_syrk_nt_upper(h, k->dtype, Kt, M, rc, rc, acc, 1, 1, tab_dev, ntiles));
+    }
+  }
+  return mgp_mirror_upper(h, k->dtype, out, acc, NZ, M, 1.0);
+}
+
 extern "C" int mgp_kmn_knm(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
                            int64_t M, void* out) {
   MGP_TRY(mgp_check_kernel(h, k));
@@ -223,6 +274,10 @@ extern "C" int mgp_kmn_knm(mgp_handle* h, const mgp_kernel* k, const void* X, in
   if (N == 0) {
     MGP_HIP(h, hipMemsetAsync(out, 0, (size_t)M * M * mgp_elem(k->dtype), h->stream));
     return MGP_OK;
+  }
+  {
+    const char* mode = getenv("MGP_CONTRACT");  // "fused" keeps the single-kernel form for A/B runs
+    if (!(mode && strcmp(mode, "fused") == 0)) return kmn_knm_two_stage(h, k, X, N, Z, M, out);
   }
   if (k->dtype == MGP_F64) return kmn_knm_t<double>(h, k, (const double*)X, N, (const double*)Z, M, (double*)out);
   return kmn_knm_t<float>(h, k, (const float*)X, N, (const float*)Z, M, (float*)out);

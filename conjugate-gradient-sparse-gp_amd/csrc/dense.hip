@@ -7,6 +7,8 @@
 // s(n^2 + 2 n Bt) bytes) done with coalesced 16-byte row reads and wavefront reductions;
 // larger Bt is a GEMM on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 128x128 tiles
 // staged through LDS.  fp32 uses v_mfma_f32_16x16x4_f32 with the same tiling.
+#include <cstdlib>
+
 #include "mgp_common.h"
 
 namespace {
@@ -185,42 +187,82 @@ struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 
-// C[Bt, n] = P[Bt, n] . A[n, n]^T  (A symmetric => P @ A).  Block tile 128(b) x 128(j), BK = 16,
-// 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles.  Both operand tiles are [row][k] row-major,
-// so global reads are 16-byte pieces along k and LDS reads are the same pattern for both.
-template <typename T>
-__global__ __launch_bounds__(256) void symm_gemm_kernel(const T* __restrict__ A, long n,
-                                                        const T* __restrict__ P, long Bt, T* __restrict__ out,
-                                                        const int* __restrict__ gate) {
+// out[m, n] (+)= P[m, K] . A[n, K]^T ("NT": both operands contiguous along the contraction index).
+// Block tile 128 x 128, BK = 16, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles; operand tiles
+// are register-prefetched one step ahead and staged through LDS with a conflict-free stride.
+// `upper_only` skips tiles strictly below the diagonal (symmetric results, mirrored by the caller).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P, long ldp, long m,
+                                                      const T* __restrict__ A, long lda, long n, long K,
+                                                      T* __restrict__ out, long ldo, int accumulate, int upper_only,
+                                                      const int* __restrict__ gate, long zstride_k, long zstride_out,
+                                                      const int* __restrict__ tile_tab, int ntiles) {
   if (gate != nullptr && *gate == 0) return;
+  // 2-D grid (tile_tab == nullptr): blockIdx.{y,x} = output tile, blockIdx.z = contraction slice.
+  // 1-D grid: blockIdx.x = slice * ntiles + entry of tile_tab (the upper-triangular tiles of a
+  // symmetric result only, so no workgroup is launched for the skipped half).
+  int by, bx, bz;
+  if (tile_tab != nullptr) {
+    bz = blockIdx.x / ntiles;
+    const int e = blockIdx.x - bz * ntiles;
+    by = tile_tab[2 * e];
+    bx = tile_tab[2 * e + 1];
+  } else {
+    by = blockIdx.y;
+    bx = blockIdx.x;
+    bz = blockIdx.z;
+    if (upper_only && bx < by) return;
+  }
+  // each slice of the contraction index has its own output buffer
+  P += (long)bz * zstride_k;
+  A += (long)bz * zstride_k;
+  out += (long)bz * zstride_out;
   constexpr int BM = 128, BN = 128, BK = 16, LDS_S = BK + 2;  // stride 18: conflict-free b64 reads
   __shared__ __attribute__((aligned(16))) T Ps[BM * LDS_S];
   __shared__ __attribute__((aligned(16))) T As[BN * LDS_S];
   using Acc = typename Mfma<T>::Acc;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long b0 = (long)blockIdx.y * BM, j0 = (long)blockIdx.x * BN;
+  const long b0 = (long)by * BM, j0 = (long)bx * BN;
 
   Acc acc[4][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[m][q] = Acc{0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) acc[mi][q] = Acc{0, 0, 0, 0};
 
-  // staging: tile has 128 rows x 16 k = 2048 elements; thread loads 8 consecutive k of one row
+  // staging: a tile is 128 rows x 16 k; thread loads 8 consecutive k of one row of each operand
   const int srow = t >> 1, skk = (t & 1) * 8;
+  const long pb = b0 + srow, aj = j0 + srow;
+  const bool p_ok = pb < m, a_ok = aj < n;
+  const T* prow = P + (p_ok ? pb : 0) * ldp;
+  const T* arow = A + (a_ok ? aj : 0) * lda;
   T pre_p[8], pre_a[8];
   auto load_tiles = [&](long k0) {
-    const long pb = b0 + srow, aj = j0 + srow;
+    const long k = k0 + skk;
+    if (VEC) {  // host guarantees K % 16 == 0, 16-byte aligned rows
+      constexpr int VW = 16 / sizeof(T);
+      using V = __attribute__((ext_vector_type(VW))) T;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const long k = k0 + skk + e;
-      pre_p[e] = (pb < Bt && k < n) ? P[pb * n + k] : (T)0;
-      pre_a[e] = (aj < n && k < n) ? A[aj * n + k] : (T)0;
+      for (int e = 0; e < 8; e += VW) {
+        const V vp = p_ok ? *reinterpret_cast<const V*>(prow + k + e) : V{};
+        const V va = a_ok ? *reinterpret_cast<const V*>(arow + k + e) : V{};
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+          pre_p[e + x] = vp[x];
+          pre_a[e + x] = va[x];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pre_p[e] = (p_ok && k + e < K) ? prow[k + e] : (T)0;
+        pre_a[e] = (a_ok && k + e < K) ? arow[k + e] : (T)0;
+      }
     }
   };
   load_tiles(0);
-  for (long k0 = 0; k0 < n; k0 += BK) {
+  for (long k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -228,32 +270,55 @@ __global__ __launch_bounds__(256) void symm_gemm_kernel(const T* __restrict__ A,
       As[srow * LDS_S + skk + e] = pre_a[e];
     }
     __syncthreads();
-    if (k0 + BK < n) load_tiles(k0 + BK);
+    if (k0 + BK < K) load_tiles(k0 + BK);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
       T af[4], bf[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = Ps[(wm * 64 + m * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+      for (int mi = 0; mi < 4; ++mi) af[mi] = Ps[(wm * 64 + mi * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bf[q] = As[(wn * 64 + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[m][q] = Mfma<T>::run(af[m], bf[q], acc[m][q]);
+        for (int q = 0; q < 4; ++q) acc[mi][q] = Mfma<T>::run(af[mi], bf[q], acc[mi][q]);
     }
   }
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long b = b0 + wm * 64 + m * 16 + Mfma<T>::row(lane, r);
+        const long b = b0 + wm * 64 + mi * 16 + Mfma<T>::row(lane, r);
         const long j = j0 + wn * 64 + q * 16 + (lane & 15);
-        if (b < Bt && j < n) out[b * n + j] = acc[m][q][r];
+        if (b < m && j < n) {
+          T* o = &out[b * ldo + j];
+          *o = accumulate ? *o + acc[mi][q][r] : acc[mi][q][r];
+        }
       }
 }
 
+template <typename T>
+inline bool gemm_vec_ok(const T* P, long ldp, const T* A, long lda, long K) {
+  return (K % 16) == 0 && ((ldp | lda) % (16 / (long)sizeof(T))) == 0 && ((((uintptr_t)P) | ((uintptr_t)A)) % 16) == 0;
+}
+
+// out[j, i] = out[i, j] for i < j (fills the lower triangle after an upper_only accumulation)
+template <typename T>
+__global__ __launch_bounds__(256) void mirror_upper_kernel(T* __restrict__ out, const T* __restrict__ slices, int nz,
+                                                           long n, T scale) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * n) return;
+  const long i = e / n, j = e - i * n;
+  if (j >= i) {
+    T v = 0;
+    for (int z = 0; z < nz; ++z) v += slices[(long)z * n * n + e];  // slices summed in index order
+    v *= scale;
+    out[e] = v;
+    if (j > i) out[j * n + i] = v;
+  }
+}
 
 // ------------------------------------------------------------------ skinny product (2 <= Bt <= 128)
 // out[Bt, n] = P[Bt, n] . A^T with A streamed from HBM exactly once (bytes s(n^2 + 2 n Bt), the
@@ -358,7 +423,12 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
   }
   if (Bt > 128) {
     dim3 grid((unsigned)((n + 127) / 128), (unsigned)((Bt + 127) / 128));
-    hipLaunchKernelGGL((symm_gemm_kernel<T>), grid, dim3(256), 0, h->stream, A, n, P, Bt, out, gate);
+    if (gemm_vec_ok<T>(P, n, A, n, n))
+      hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(256), 0, h->stream, P, n, Bt, A, n, n, n, out, n, 0, 0,
+                         gate, 0L, 0L, (const int*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(256), 0, h->stream, P, n, Bt, A, n, n, n, out, n, 0,
+                         0, gate, 0L, 0L, (const int*)nullptr, 0);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;
   }
@@ -409,6 +479,41 @@ int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, c
   if (dtype == MGP_F64)
     return symm_gemv_rows_t<double>(h, (const double*)A, n, (const double*)p, rb, re, alpha, (double*)out, gate);
   return symm_gemv_rows_t<float>(h, (const float*)A, n, (const float*)p, rb, re, (float)alpha, (float*)out, gate);
+}
+
+// out[n, n] (+)= Kt[n, K] . Kt[n, K]^T on upper-triangular tiles (contract.hip accumulates row chunks)
+int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64_t K, int64_t ld, void* out,
+                      int accumulate, int nz, const int* tile_tab, int ntiles) {
+  // nz slices of K columns each (Kt row = nz*K columns wide, ld), slice z accumulates into out + z*n*n;
+  // tile_tab lists the upper-triangular 128x128 tiles (device, [ntiles][2])
+  dim3 grid((unsigned)(ntiles * nz));
+  const long zk = K, zo = n * n;
+  const int upper = 1;
+#define MGP_SYRK(TT, VV)                                                                                      \
+  hipLaunchKernelGGL((gemm_nt_kernel<TT, VV>), grid, dim3(256), 0, h->stream, (const TT*)Kt, ld, n, (const TT*)Kt, \
+                     ld, n, K, (TT*)out, n, accumulate, upper, (const int*)nullptr, zk, zo, tile_tab, ntiles)
+  if (dtype == MGP_F64) {
+    if (gemm_vec_ok<double>((const double*)Kt, ld, (const double*)Kt, ld, K)) MGP_SYRK(double, true);
+    else MGP_SYRK(double, false);
+  } else {
+    if (gemm_vec_ok<float>((const float*)Kt, ld, (const float*)Kt, ld, K)) MGP_SYRK(float, true);
+    else MGP_SYRK(float, false);
+  }
+#undef MGP_SYRK
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale) {
+  const long tot = n * n;
+  if (dtype == MGP_F64)
+    hipLaunchKernelGGL((mirror_upper_kernel<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (double*)out, (const double*)slices, nz, n, scale);
+  else
+    hipLaunchKernelGGL((mirror_upper_kernel<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (float*)out, (const float*)slices, nz, n, (float)scale);
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
 }
 
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,

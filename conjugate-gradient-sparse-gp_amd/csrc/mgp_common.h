@@ -32,6 +32,10 @@ struct mgp_handle {
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
   int sweep_mode = 0;
+  // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
+  // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)
+  size_t contract_panel_mb = 2048;
+  int contract_nz = 16;
   int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
   bool prof_on = false;
@@ -150,6 +154,9 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
 int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long na, const double* B, long nb,
                        const double* W, long w_sj, long w_sr, int R, double* out, long o_si, long o_sr,
                        double alpha, const double* addend, long ad_si, long ad_sr, const int* gate);
+int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64_t K, int64_t ld, void* out,
+                      int accumulate, int nz, const int* tile_tab, int ntiles);
+int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale);
 int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
                            double alpha, void* out, const int* gate);
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
