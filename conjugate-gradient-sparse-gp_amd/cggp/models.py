@@ -203,13 +203,16 @@ class CGGP(ClusterGP):
         const = torch.log(self.diag_variance).sum().item()  # :321
         return 0.5 * (quad - trace + logdet - const)  # :322
 
-    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):  # :324-354
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False, _shared=None):  # :324-354
         assert not full_output_cov
         iv, kernel = self.inducing_variable, self.kernel
-        _, KmmLambda = self._Kmm_and_KmmLambda()  # :333,337
-        Kmn = Kuf(iv, kernel, Xnew)  # :334
         cg = self.conjugate_gradient
-        a = cg(KmmLambda, self.pseudo_u)  # :339
+        if _shared is None:
+            _, KmmLambda = self._Kmm_and_KmmLambda()  # :333,337
+            a = cg(KmmLambda, self.pseudo_u)  # :339
+        else:  # predict_f_batched: the N-free pieces are the same for every batch
+            KmmLambda, a = _shared
+        Kmn = Kuf(iv, kernel, Xnew)  # :334
         W = cg(KmmLambda, Kmn)  # :340
         if not full_cov:
             fvar = (kernel.K_diag(Xnew) - ops.colwise_dot(Kmn, W))[:, None]  # :343-345
@@ -217,6 +220,18 @@ class CGGP(ClusterGP):
             fvar = (kernel.K(Xnew) - Kmn.t() @ W)[None, ...]  # :347-349
         fmu = ops.knm_matvec(kernel.spec(Xnew.shape[1]), Xnew, iv.Z, a)  # Kmn^T a, :351 (row M1)
         return fmu + self._mean(Xnew), fvar
+
+    def predict_f_batched(self, X, batch_size):
+        """`batch_posterior_computation` (`cggp/cli_utils.py:426-436`); (Kmm+Lambda) and its solve
+        against pseudo_u do not depend on the batch and are formed once."""
+        _, KmmLambda = self._Kmm_and_KmmLambda()
+        shared = (KmmLambda, self.conjugate_gradient(KmmLambda, self.pseudo_u))
+        means, variances = [], []
+        for s in range(0, X.shape[0], batch_size):
+            mu, var = self.predict_f(X[s:s + batch_size], _shared=shared)
+            means.append(mu)
+            variances.append(var)
+        return torch.cat(means, 0), torch.cat(variances, 0)
 
     def elbo(self, data, probes=None):
         x, y = data

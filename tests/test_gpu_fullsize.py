@@ -100,3 +100,42 @@ def test_fullsize_fp32_c4_slice():
     ko = ok.Kernel("se", 1.0, np.ones(D))
     ref = ko.K(syn.X[rows].astype(np.float64), syn.Z.astype(np.float64)) @ v.cpu().numpy().astype(np.float64)
     assert np.max(np.abs(u.cpu().numpy()[rows] - ref)) / np.max(np.abs(ref)) < 2e-4
+
+
+def test_config_c1_end_to_end_against_oracle():
+    """BASELINE.json configs[0]: synthetic 1-D, N=2048, M=128, SE, fp64 -- SGPR and CDGP, whole
+    pipeline (assignment, statistics, CG solves, predictive mean/variance) against the oracle."""
+    from cggp import kernels, synthetic
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import CGGP, SGPR
+    from cggp.optimize import assign_inducing_parameters, oips_update_inducing_parameters
+    from oracle import cg as ocg, cluster as oc, models as om
+    N, D, M, dt, kname = synthetic.CONFIGS["C1"]
+    syn = synthetic.make_inputs(N, D, M, dt)
+    X, y, Z = (torch.from_numpy(a).to(dev()) for a in (syn.X, syn.y, syn.Z))
+    kern, ko = kernels.SquaredExponential(1.0, [1.0]), ok.Kernel("se", 1.0, np.ones(1))
+    cg, cgo = ConjugateGradient(1e-15, max_iterations=20000), ocg.ConjugateGradient(1e-15, max_iterations=20000)
+    # CDGP
+    m = CGGP(kern, 0.1, Z, cg, num_probes=None, num_data=N)
+    assign_inducing_parameters(m, *oips_update_inducing_parameters(m, (X, y), Z))
+    idx = oc.nearest_centre_sqdist(syn.Z, syn.X)
+    u, counts = oc.cluster_stats(idx, syn.y, M)
+    assert np.array_equal(m.cluster_counts.cpu().numpy(), counts)
+    assert np.max(np.abs(m.pseudo_u.cpu().numpy() - u)) < 1e-12
+    ref = om.CGGP(ko, 0.1, syn.Z, cgo, num_probes=None, pseudo_u=u, cluster_counts=counts, num_data=N)
+    Xs = syn.X[::8]
+    mu, var = m.predict_f(torch.from_numpy(Xs).to(dev()))
+    mu0, var0 = ref.predict_f(Xs)
+    assert np.max(np.abs(mu.cpu().numpy() - mu0)) / np.max(np.abs(mu0)) < 1e-6
+    # var = k** - sum(Kmn * W) cancels to ~5e-3 of k** = 1 here; both CGs stop at the reference's
+    # guard floor (||r|| ~ 1e-8), so the meaningful scale for 1e-6 is k**, and ~1e-5 on var itself
+    assert np.max(np.abs(var.cpu().numpy() - var0)) / 1.0 < 1e-6
+    assert np.max(np.abs(var.cpu().numpy() - var0)) / np.max(np.abs(var0)) < 1e-5
+    # SGPR: CG form here vs GPflow's two-Cholesky closed form in the oracle
+    s = SGPR((X, y), kern, Z, 0.1, cg, jitter=1e-6)
+    smu, svar = s.predict_f(torch.from_numpy(Xs).to(dev()))
+    r = om.SGPR((syn.X, syn.y), ko, syn.Z, 0.1, jitter=1e-6)
+    rmu, rvar = r.predict_f(Xs)
+    assert np.max(np.abs(smu.cpu().numpy() - rmu)) / np.max(np.abs(rmu)) < 1e-5
+    assert np.max(np.abs(svar.cpu().numpy() - rvar)) / np.max(np.abs(rvar)) < 1e-4
+    assert abs(s.elbo() - r.elbo()) / abs(r.elbo()) < 1e-8

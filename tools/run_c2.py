@@ -1,0 +1,34 @@
+"""Config C2 end to end: CDGP, RBF, N=100k, D=8, M=2048, fp64 -- assignment, statistics, predictive
+mean and variance for every row through the device CG (reference thresholds)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "conjugate-gradient-sparse-gp_amd"))
+import numpy as np, torch
+from cggp import kernels, synthetic
+from cggp.conjugate_gradient import ConjugateGradient
+from cggp.models import CGGP, rmse_nlpd
+from cggp.optimize import oips_update_inducing_parameters, assign_inducing_parameters
+
+N, D, M, dt, kname = synthetic.CONFIGS["C2"]
+syn = synthetic.make_inputs(N, D, M, dt)
+dev = torch.device("cuda:0")
+X, y, Z = (torch.from_numpy(a).to(dev) for a in (syn.X, syn.y, syn.Z))
+kern = kernels.SquaredExponential(1.0, [1.0] * D)
+model = CGGP(kern, 0.1, Z, ConjugateGradient(1e-6, check_every=16), num_probes=5, num_data=N)
+
+
+def timed(name, fn):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    print(f"{name}: {1e3 * (time.perf_counter() - t):.1f} ms", flush=True)
+    return r
+
+
+iv, means, counts = timed("assign + cluster statistics", lambda: oips_update_inducing_parameters(model, (X, y), Z))
+assign_inducing_parameters(model, iv, means, counts)
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+mu, var = timed(f"predict_f_batched (all {N} rows, batch {batch})", lambda: model.predict_f_batched(X, batch))
+st = model.conjugate_gradient.last_stats
+print("last batch CG steps:", int(st[0]))
+kl = timed("prior_kl (5 Hutchinson probes)", lambda: model.prior_kl())
+rmse = float(torch.sqrt(((y - mu) ** 2).mean()))
+print("train rmse", rmse, "mean var", float(var.mean()), "kl", kl)
