@@ -177,10 +177,20 @@ def main():
         (a, (csteps, cerr)), t_cg = timed(lambda: cgm.solve_with_stats(KL, u))
         res = KL @ a - u
         (_, t_mean) = timed(lambda: ops.knm_matvec(spec, X, Z, a))
+        # C3's "64 Hutchinson log-det probe vectors": trace estimator of models.py:308-314 and the
+        # log-det-gradient estimator of models.py:37-44, both one 64-RHS CG on (Kmm + Lambda)
+        from cggp.models import CGGP
+        mdl = CGGP(kern, syn.noise_variance, Z, cgm, num_probes=64, pseudo_u=u, cluster_counts=counts[:, None],
+                   num_data=N)
+        probes = torch.from_numpy(synthetic.make_probes(M, 64, dtype_name)).to(dev)
+        (kl, t_kl) = timed(lambda: mdl.prior_kl(probes=probes))
+        (_, t_ldg) = timed(lambda: mdl.logdet_gradient(1.0, probes=probes))
+        cdgp_probe = {"prior_kl_64_probes_ms": t_kl, "prior_kl": kl, "logdet_gradient_64_probes_ms": t_ldg,
+                      "probe_cg_iterations": int(cgm.last_stats[0])}
         cdgp = {"assign_and_stats_ms": t_assign, "kuu_lambda_ms": t_k, "cg_iterations": int(csteps),
                 "cg_ms": t_cg, "cg_half_rz_final": float(cerr.max().item()),
                 "true_half_residual_sq": 0.5 * float((res * res).sum().item()),
-                "predict_mean_all_local_rows_ms": t_mean}
+                "predict_mean_all_local_rows_ms": t_mean, **cdgp_probe}
     except Exception as e:  # the headline number must not depend on this leg
         cdgp = {"error": repr(e)}
 
