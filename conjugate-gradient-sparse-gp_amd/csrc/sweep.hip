@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
   }
   constexpr int TB = TileCfg<DP>::TB;
   constexpr int RPT = TileCfg<DP>::RPT;
-  constexpr int UJ = TileCfg<DP>::UJ;
+  // fp32 bodies are a handful of instructions per pair: unroll so LDS latency hides behind them
+  constexpr int UJ = (sizeof(T) == 4 && DP <= 8) ? 4 : TileCfg<DP>::UJ;
   constexpr int PS = (DP + 1 + RC + 1) & ~1;  // per-point LDS stride, even => 16-B aligned rows
   __shared__ __attribute__((aligned(16))) T tile[TB * PS];
   // fp64: 2^(i/2048) table for mgp_exp2_tab (16 KB); fp32 uses v_exp_f32 and no table
