@@ -101,6 +101,7 @@ SIGNATURES = {
     "mgp_dot_all": (_I, [_P, _I, _P, _P, _L, ctypes.POINTER(_D)]),
     "mgp_nearest_center": (_I, [_P, _KP, _I, _P, _L, _P, _L, _P, _P]),
     "mgp_cluster_stats": (_I, [_P, _I, _P, _P, _L, _L, _P, _P]),
+    "mgp_k_dense_vjp": (_I, [_P, _KP, _P, _L, _P, _L, _P, _L, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),
 }

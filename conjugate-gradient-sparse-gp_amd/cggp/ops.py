@@ -107,6 +107,21 @@ def k_dense(spec, A, B, jitter=0.0, diag_add=None):
     return out
 
 
+def k_dense_vjp(spec, A, B, G):
+    """(dL/dvariance: float, dL/dlengthscales: list[D]) for K = k(A,B) given G = dL/dK (row F2)."""
+    A = _points(A, "A", spec.D)
+    B = _points(B, "B", spec.D, A.dtype)
+    G = _hip.check_tensor(G, "G", dtype=A.dtype, shape=(A.shape[0], B.shape[0]))
+    dvar = ctypes.c_double(0.0)
+    dls = (ctypes.c_double * _hip.MGP_MAX_D)()
+    if A.shape[0] and B.shape[0]:
+        hd = _hip.get_handle(A.device)
+        k = spec.struct(_hip.dtype_code(A))
+        hd.check(hd.lib.mgp_k_dense_vjp(hd.h, ctypes.byref(k), _hip.ptr(A), A.shape[0], _hip.ptr(B), B.shape[0],
+                                        _hip.ptr(G), B.shape[0], ctypes.byref(dvar), dls))
+    return dvar.value, [dls[d] for d in range(spec.D)]
+
+
 def kmn_knm(spec, X, Z):
     """out [M,M] = k(Z,X) k(X,Z) on the matrix cores (row S1)."""
     X = _points(X, "X", spec.D)

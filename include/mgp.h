@@ -181,6 +181,14 @@ int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const 
 int mgp_cluster_stats(mgp_handle* h, int dtype, const int64_t* idx, const void* y, int64_t N,
                       int64_t M, void* sums, void* counts);
 
+/* ---- next row F2: hyper-parameter gradient of a kernel block ---------------------------------
+ * Given G = dL/dK for K = k(A,B) [na, nb] (leading dimension ldg), returns (host doubles)
+ * dL/dvariance and dL/dlengthscales[D] -- the vector-Jacobian product autodiff takes through
+ * gpflow's kernel in the reference's training step (cggp/optimize.py:198-254 over
+ * cggp/models.py:125-134,293-354).  Fused reduction; synchronises the stream. */
+int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B,
+                    int64_t nb, const void* G, int64_t ldg, double* dvariance, double* dlengthscales);
+
 /* ---- measurement (bench.py): HIP events around every launch of the fused sweep kernel ------
  * While enabled, each sweep launch is bracketed by two events on the handle's stream;
  * mgp_profile_read synchronises the stream, returns the number of bracketed launches and the

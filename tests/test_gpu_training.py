@@ -1,0 +1,115 @@
+"""Next row F2: gradients through the kernel blocks and the CG model, and the Adam loop.
+
+The reference's own gradient tests (`cggp/cg_test.py:34-46,68-77`) compare CG-based gradients
+with autodiff through direct solves; here the autograd gradient of the CG model's ELBO is compared
+with finite differences of the oracle's Cholesky twin (whose value includes log|Kmm+Lambda|, which
+the CG model carries only in its gradient, `cggp/models.py:30-46`)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cluster as oc, kernels as ok, models as om
+
+pytestmark = pytest.mark.gpu
+KINDS = ["se", "matern12", "matern32", "matern52"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+@pytest.mark.parametrize("name", KINDS)
+@pytest.mark.parametrize("D", [1, 3, 8])
+def test_k_dense_vjp_matches_finite_differences(name, D):
+    from cggp import ops
+    rng = np.random.default_rng(0)
+    A, B = rng.standard_normal((150, D)), rng.standard_normal((60, D)) + 0.3
+    G = rng.standard_normal((150, 60))
+    var, ls = 1.3, rng.random(D) + 0.7
+    spec = ops.KernelSpec(name, var, ls.tolist(), D)
+    dvar, dls = ops.k_dense_vjp(spec, T(A), T(B), T(G))
+    f = lambda v, l: float(np.sum(G * ok.Kernel(name, v, l).K(A, B)))
+    h = 1e-6
+    assert abs(dvar - (f(var + h, ls) - f(var - h, ls)) / (2 * h)) < 1e-6 * max(1.0, abs(dvar))
+    for d in range(D):
+        e = np.zeros(D)
+        e[d] = h
+        fd = (f(var, ls + e) - f(var, ls - e)) / (2 * h)
+        assert abs(dls[d] - fd) < 2e-6 * max(1.0, abs(fd)), (d, dls[d], fd)
+
+
+def _problem(name, N=240, D=2, M=14, seed=1):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    y = np.sin(X).sum(1, keepdims=True) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.choice(N, M, replace=False)]
+    idx = oc.nearest_centre_sqdist(Z, X)
+    u, counts = oc.cluster_stats(idx, y, M)
+    return X, y, Z, u, counts
+
+
+@pytest.mark.parametrize("name", ["se", "matern32", "matern52"])
+def test_elbo_gradient_matches_cholesky_twin(name):
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import TrainableCGGP
+    X, y, Z, u, counts = _problem(name)
+    var, ls, s2 = 1.2, np.array([0.9, 1.4]), 0.15
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32, "matern52": kernels.Matern52}[name]
+    m = TrainableCGGP(cls(var, ls), s2, T(Z), ConjugateGradient(1e-15, max_iterations=5000), num_probes=None,
+                      pseudo_u=T(u), cluster_counts=T(counts), num_data=X.shape[0])
+    xb, yb = X[:100], y[:100]
+    e = m.elbo((T(xb), T(yb)))
+    e.backward()
+    sig = lambda p: torch.sigmoid(p.raw.detach())
+    g_var = float(m.kernel.variance_p.raw.grad / sig(m.kernel.variance_p))
+    g_ls = (m.kernel.lengthscales_p.raw.grad / sig(m.kernel.lengthscales_p)).numpy()
+    g_s2 = float(m.noise_p.raw.grad / sig(m.noise_p))
+
+    def twin(v, l, s):
+        t = om.ClusterGP(ok.Kernel(name, v, l), s, Z, pseudo_u=u, cluster_counts=counts, num_data=X.shape[0])
+        return float(t.elbo((xb, yb)))
+
+    # value: the CG model omits 0.5*log|Kmm+Lambda| (models.py:46); its gradient does not
+    KL = om.add_diagonal(ok.Kuu(Z, ok.Kernel(name, var, ls)), (s2 / counts)[:, 0])
+    assert abs(float(e) - (twin(var, ls, s2) + 0.5 * np.linalg.slogdet(KL)[1])) < 1e-6 * abs(float(e))
+    h = 1e-5
+    fd_var = (twin(var + h, ls, s2) - twin(var - h, ls, s2)) / (2 * h)
+    fd_s2 = (twin(var, ls, s2 + h) - twin(var, ls, s2 - h)) / (2 * h)
+    assert abs(g_var - fd_var) < 1e-4 * max(1.0, abs(fd_var)), (g_var, fd_var)
+    assert abs(g_s2 - fd_s2) < 1e-4 * max(1.0, abs(fd_s2)), (g_s2, fd_s2)
+    for d in range(2):
+        dl = np.zeros(2)
+        dl[d] = h
+        fd = (twin(var, ls + dl, s2) - twin(var, ls - dl, s2)) / (2 * h)
+        assert abs(g_ls[d] - fd) < 1e-4 * max(1.0, abs(fd)), (d, g_ls[d], fd)
+
+
+def test_adam_training_reduces_the_loss_and_updates_inducing_parameters():
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.optimize import oips_update_inducing_parameters
+    from cggp.training import TrainableCGGP, train_using_adam_and_update
+    X, y, Z, u, counts = _problem("se", N=2000, D=2, M=32, seed=2)
+    m = TrainableCGGP(kernels.SquaredExponential(0.3, [3.0, 3.0]), 1.0, T(Z), ConjugateGradient(1e-10),
+                      num_probes=5, pseudo_u=T(u), cluster_counts=T(counts), num_data=2000)
+    calls = []
+
+    def update_fn():
+        _, means, c = oips_update_inducing_parameters(m.frozen_model(), (T(X), T(y)), T(Z))
+        m.pseudo_u, m.cluster_counts = means, c
+        calls.append(1)
+
+    losses = train_using_adam_and_update((T(X), T(y)), m, iterations=40, batch_size=500, learning_rate=0.05,
+                                         update_fn=update_fn, update_during_training=True)
+    assert len(losses) == 40 and len(calls) == 41
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert all(np.isfinite(losses))
+    fm = m.frozen_model()
+    mu, var = fm.predict_f(T(X[:50]))
+    assert torch.isfinite(mu).all() and torch.isfinite(var).all()
