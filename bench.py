@@ -32,10 +32,11 @@ import torch.distributed as dist  # noqa: E402
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet (== fp64 matrix peak); MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
-# What csrc/sweep.hip executes per pair for the SE kernel (DESIGN.md "kernel 1"): distance D fma + 1 add;
-# exp2 by table: max, 3 add, 2 fma, mul, fma, ldexp (9 fp64 instr, 12 flop) + and/ashr/lshl; RC accumulate fma
-EXEC_FLOPS_PER_PAIR = lambda D, R: (2 * D + 1) + 12 + 2 * R
-EXEC_VALU_INSTR_PER_PAIR = lambda D, R: (D + 1) + 9 + 3 + R
+# What csrc/sweep.hip executes per pair on the SE fast path: distance D fma; exp2 by table with
+# |a|^2 folded into the magic constant: 3 add, 2 fma, mul, fma, ldexp (8 fp64 instr, 11 flop) + and/ashr/lshl;
+# RC accumulate fma
+EXEC_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
+EXEC_VALU_INSTR_PER_PAIR = lambda D, R: D + 8 + 3 + R
 NUM_SIMDS, MAX_CLOCK_HZ, FP64_CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
 
 
@@ -47,6 +48,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--convergence-cap", type=int, default=0, help="iteration cap of the convergence leg (0 = M)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -56,11 +59,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from cggp import _hip, kernels, ops, parallel, synthetic
     from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
@@ -106,6 +114,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if args.backend != "nccl":
+            tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -140,7 +150,7 @@ def main():
     # ---- bounded convergence report (informational): real stopping rule, thr = 1e-6
     conv = None
     if rank == 0 or world > 1:
-        cap = M  # the reference's default cap: max_iterations = n (conjugate_gradient.py:190-192)
+        cap = args.convergence_cap or M  # reference default cap: max_iterations = n (conjugate_gradient.py:190-192)
         tc = time.perf_counter()
         sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, max_iterations=cap, max_steps_cycle=cap + 1,
                                                check_every=64)
