@@ -188,10 +188,11 @@ struct Mfma<float> {
 };
 
 // out[m, n] (+)= P[m, K] . A[n, K]^T ("NT": both operands contiguous along the contraction index).
-// Block tile 128 x 128, BK = 16, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles; operand tiles
-// are register-prefetched one step ahead and staged through LDS with a conflict-free stride.
-// `upper_only` skips tiles strictly below the diagonal (symmetric results, mirrored by the caller).
-template <typename T, bool VEC>
+// Block tile (32 WT) x (32 WT), BK = 16, 4 waves as 2x2, each wave WT x WT MFMA tiles of 16x16
+// (WT = 4: 128x128 tile, the throughput shape; WT = 2: 64x64, used when the 128-tile grid would
+// leave CUs idle).  Operand tiles are register-prefetched one step ahead and staged through LDS
+// with a conflict-free stride.  `upper_only` skips tiles strictly below the diagonal.
+template <typename T, bool VEC, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P, long ldp, long m,
                                                       const T* __restrict__ A, long lda, long n, long K,
                                                       T* __restrict__ out, long ldo, int accumulate, int upper_only,
@@ -217,34 +218,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
   P += (long)bz * zstride_k;
   A += (long)bz * zstride_k;
   out += (long)bz * zstride_out;
-  constexpr int BM = 128, BN = 128, BK = 16, LDS_S = BK + 2;  // stride 18: conflict-free b64 reads
+  constexpr int BM = 32 * WT, BK = 16, LDS_S = BK + 2;  // stride 18: conflict-free b64 reads
+  constexpr int EPT = BM * BK / 256;                      // elements per thread and operand per step
   __shared__ __attribute__((aligned(16))) T Ps[BM * LDS_S];
-  __shared__ __attribute__((aligned(16))) T As[BN * LDS_S];
+  __shared__ __attribute__((aligned(16))) T As[BM * LDS_S];
   using Acc = typename Mfma<T>::Acc;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long b0 = (long)by * BM, j0 = (long)bx * BN;
+  const long b0 = (long)by * BM, j0 = (long)bx * BM;
 
-  Acc acc[4][4];
+  Acc acc[WT][WT];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < WT; ++mi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[mi][q] = Acc{0, 0, 0, 0};
+    for (int q = 0; q < WT; ++q) acc[mi][q] = Acc{0, 0, 0, 0};
 
-  // staging: a tile is 128 rows x 16 k; thread loads 8 consecutive k of one row of each operand
-  const int srow = t >> 1, skk = (t & 1) * 8;
+  // staging: a tile is BM rows x 16 k; a thread loads EPT consecutive k of one row of each operand
+  const int srow = t / (BK / EPT), skk = (t % (BK / EPT)) * EPT;
   const long pb = b0 + srow, aj = j0 + srow;
   const bool p_ok = pb < m, a_ok = aj < n;
   const T* prow = P + (p_ok ? pb : 0) * ldp;
   const T* arow = A + (a_ok ? aj : 0) * lda;
-  T pre_p[8], pre_a[8];
+  T pre_p[EPT], pre_a[EPT];
   auto load_tiles = [&](long k0) {
     const long k = k0 + skk;
     if (VEC) {  // host guarantees K % 16 == 0, 16-byte aligned rows
       constexpr int VW = 16 / sizeof(T);
       using V = __attribute__((ext_vector_type(VW))) T;
 #pragma unroll
-      for (int e = 0; e < 8; e += VW) {
+      for (int e = 0; e < EPT; e += VW) {
         const V vp = p_ok ? *reinterpret_cast<const V*>(prow + k + e) : V{};
         const V va = a_ok ? *reinterpret_cast<const V*>(arow + k + e) : V{};
 #pragma unroll
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         pre_p[e] = (p_ok && k + e < K) ? prow[k + e] : (T)0;
         pre_a[e] = (a_ok && k + e < K) ? arow[k + e] : (T)0;
       }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
   for (long k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       Ps[srow * LDS_S + skk + e] = pre_p[e];
       As[srow * LDS_S + skk + e] = pre_a[e];
     }
@@ -273,25 +275,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
     if (k0 + BK < K) load_tiles(k0 + BK);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      T af[4], bf[4];
+      T af[WT], bf[WT];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = Ps[(wm * 64 + mi * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+      for (int mi = 0; mi < WT; ++mi)
+        af[mi] = Ps[(wm * 16 * WT + mi * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bf[q] = As[(wn * 64 + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+      for (int q = 0; q < WT; ++q) bf[q] = As[(wn * 16 * WT + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < WT; ++mi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[mi][q] = Mfma<T>::run(af[mi], bf[q], acc[mi][q]);
+        for (int q = 0; q < WT; ++q) acc[mi][q] = Mfma<T>::run(af[mi], bf[q], acc[mi][q]);
     }
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < WT; ++mi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < WT; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long b = b0 + wm * 64 + mi * 16 + Mfma<T>::row(lane, r);
-        const long j = j0 + wn * 64 + q * 16 + (lane & 15);
+        const long b = b0 + wm * 16 * WT + mi * 16 + Mfma<T>::row(lane, r);
+        const long j = j0 + wn * 16 * WT + q * 16 + (lane & 15);
         if (b < m && j < n) {
           T* o = &out[b * ldo + j];
           *o = accumulate ? *o + acc[mi][q][r] : acc[mi][q][r];
@@ -302,6 +305,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
 template <typename T>
 inline bool gemm_vec_ok(const T* P, long ldp, const T* A, long lda, long K) {
   return (K % 16) == 0 && ((ldp | lda) % (16 / (long)sizeof(T))) == 0 && ((((uintptr_t)P) | ((uintptr_t)A)) % 16) == 0;
+}
+
+// out[m, n] (+)= P[m,K] . A[n,K]^T : picks the 64x64 tile when 128x128 tiles would not fill the CUs
+template <typename T>
+int gemm_nt_launch(mgp_handle* h, const T* P, long ldp, long m, const T* A, long lda, long n, long K, T* out,
+                   long ldo, int accumulate, const int* gate) {
+  const bool vec = gemm_vec_ok<T>(P, ldp, A, lda, K);
+  const long big = ((n + 127) / 128) * ((m + 127) / 128);
+#define MGP_GEMM(VV, WTV)                                                                                        \
+  do {                                                                                                           \
+    dim3 grid((unsigned)((n + 32 * WTV - 1) / (32 * WTV)), (unsigned)((m + 32 * WTV - 1) / (32 * WTV)));         \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, VV, WTV>), grid, dim3(256), 0, h->stream, P, ldp, m, A, lda, n, K, out, \
+                       ldo, accumulate, 0, gate, 0L, 0L, (const int*)nullptr, 0);                                \
+  } while (0)
+  if (big >= 2L * h->num_cus) {
+    if (vec) MGP_GEMM(true, 4);
+    else MGP_GEMM(false, 4);
+  } else {
+    if (vec) MGP_GEMM(true, 2);
+    else MGP_GEMM(false, 2);
+  }
+#undef MGP_GEMM
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
 }
 
 // out[j, i] = out[i, j] for i < j (fills the lower triangle after an upper_only accumulation)
@@ -422,15 +449,7 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
     return MGP_OK;
   }
   if (Bt > 128) {
-    dim3 grid((unsigned)((n + 127) / 128), (unsigned)((Bt + 127) / 128));
-    if (gemm_vec_ok<T>(P, n, A, n, n))
-      hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(256), 0, h->stream, P, n, Bt, A, n, n, n, out, n, 0, 0,
-                         gate, 0L, 0L, (const int*)nullptr, 0);
-    else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(256), 0, h->stream, P, n, Bt, A, n, n, n, out, n, 0,
-                         0, gate, 0L, 0L, (const int*)nullptr, 0);
-    MGP_LAUNCH_CHECK(h);
-    return MGP_OK;
+    return gemm_nt_launch<T>(h, P, n, Bt, A, n, n, n, out, n, 0, gate);
   }
   constexpr int VECW = 16 / sizeof(T);
   const bool vec = (n % VECW) == 0 && (((uintptr_t)A) % 16) == 0;
@@ -490,7 +509,7 @@ int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64
   const long zk = K, zo = n * n;
   const int upper = 1;
 #define MGP_SYRK(TT, VV)                                                                                      \
-  hipLaunchKernelGGL((gemm_nt_kernel<TT, VV>), grid, dim3(256), 0, h->stream, (const TT*)Kt, ld, n, (const TT*)Kt, \
+  hipLaunchKernelGGL((gemm_nt_kernel<TT, VV, 4>), grid, dim3(256), 0, h->stream, (const TT*)Kt, ld, n, (const TT*)Kt, \
                      ld, n, K, (TT*)out, n, accumulate, upper, (const int*)nullptr, zk, zo, tile_tab, ntiles)
   if (dtype == MGP_F64) {
     if (gemm_vec_ok<double>((const double*)Kt, ld, (const double*)Kt, ld, K)) MGP_SYRK(double, true);

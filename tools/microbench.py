@@ -23,7 +23,7 @@ def timeit(fn, reps=5, warm=2):
 
 which = sys.argv[1:] or ["gemm", "gemv", "kdense", "contract", "sweeps"]
 if "gemm" in which:
-    for n, Bt, dt in [(2048, 4096, torch.float64), (4096, 4096, torch.float64), (4096, 1024, torch.float64),
+    for n, Bt, dt in [(2048, 4096, torch.float64), (4096, 4096, torch.float64), (4096, 1024, torch.float64), (2048, 1000, torch.float64), (2048, 300, torch.float64),
                       (4096, 64, torch.float64), (4096, 4096, torch.float32)]:
         A = torch.randn(n, n, dtype=dt, device=dev); A = A + A.t()
         P = torch.randn(Bt, n, dtype=dt, device=dev)
