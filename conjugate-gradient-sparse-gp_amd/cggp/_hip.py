@@ -11,7 +11,8 @@ import threading
 
 import torch
 
-MGP_MAX_D = 32
+MGP_MAX_D = 512
+MGP_FUSED_MAX_D = 32
 F32, F64 = 0, 1
 SE, MATERN12, MATERN32, MATERN52 = 0, 1, 2, 3
 COLS, ROWS = 0, 1
@@ -219,7 +220,7 @@ def make_kernel_struct(kind, dtype_c, D, variance, lengthscales):
     if len(ls) != D:
         raise ValueError(f"lengthscales has {len(ls)} entries for D={D}")
     if D > MGP_MAX_D:
-        raise ValueError(f"D={D} > {MGP_MAX_D} is not supported by the fused sweeps")
+        raise ValueError(f"D={D} > {MGP_MAX_D} is not supported")
     for i, v in enumerate(ls):
         k.lengthscales[i] = v
     return k

@@ -39,6 +39,12 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
       return MGP_E_NOMEM;
     }
   }
+  if (hipMalloc((void**)&h->dparams, MGP_MAX_D * sizeof(double)) != hipSuccess) {
+    (void)hipFree(h->ones);
+    (void)hipHostFree(h->host_flag);
+    delete h;
+    return MGP_E_NOMEM;
+  }
   *out = h;
   return MGP_OK;
 }
@@ -49,8 +55,10 @@ extern "C" int mgp_destroy(mgp_handle* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->cg) (void)hipFree(h->cg);
   if (h->opws) (void)hipFree(h->opws);
+  if (h->gen) (void)hipFree(h->gen);
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);
+  if (h->dparams) (void)hipFree(h->dparams);
   for (auto& pr : h->prof_ev) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);

@@ -150,7 +150,7 @@ int nearest_t(mgp_handle* h, const mgp_kernel* k, int dist_type, const T* X, lon
               T* best) {
   SweepParams prm = mgp_make_params(k);
   if (dist_type <= 1) {  // raw inputs: no lengthscale, no profile scale
-    for (int d = 0; d < MGP_MAX_D; ++d) prm.inv_ls[d] = d < k->D ? 1.0 : 0.0;
+    for (int d = 0; d < MGP_FUSED_MAX_D; ++d) prm.inv_ls[d] = d < k->D ? 1.0 : 0.0;
   }
   switch (k->kind) {
     case MGP_SE: return nearest_dp<T, 0>(h, prm, k->D, dist_type, X, N, Z, M, idx, best);
@@ -187,6 +187,7 @@ int cluster_stats_t(mgp_handle* h, const long* idx, const T* y, long N, long M, 
 extern "C" int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const void* X, int64_t N,
                                   const void* Z, int64_t M, int64_t* idx, void* best) {
   MGP_TRY(mgp_check_kernel(h, k));
+  MGP_TRY(mgp_check_fused_dim(h, k, "nearest_center"));
   if (dist_type < 0 || dist_type > 3) return mgp_fail(h, MGP_E_BADARG, "bad dist_type %d", dist_type);
   if (N < 0 || M <= 0) return mgp_fail(h, MGP_E_SHAPE, "nearest_center needs N >= 0 and M > 0");
   if (N == 0) return MGP_OK;

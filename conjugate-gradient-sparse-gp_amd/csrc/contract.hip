@@ -277,7 +277,7 @@ extern "C" int mgp_kmn_knm(mgp_handle* h, const mgp_kernel* k, const void* X, in
   }
   {
     const char* mode = getenv("MGP_CONTRACT");  // "fused" keeps the single-kernel form for A/B runs
-    if (!(mode && strcmp(mode, "fused") == 0)) return kmn_knm_two_stage(h, k, X, N, Z, M, out);
+    if (k->D > MGP_FUSED_MAX_D || !(mode && strcmp(mode, "fused") == 0)) return kmn_knm_two_stage(h, k, X, N, Z, M, out);
   }
   if (k->dtype == MGP_F64) return kmn_knm_t<double>(h, k, (const double*)X, N, (const double*)Z, M, (double*)out);
   return kmn_knm_t<float>(h, k, (const float*)X, N, (const float*)Z, M, (float*)out);

@@ -523,6 +523,15 @@ int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64
   return MGP_OK;
 }
 
+int mgp_gemm_nt(mgp_handle* h, int dtype, const void* P, int64_t ldp, int64_t m, const void* A, int64_t lda, int64_t n,
+                int64_t K, void* out, int64_t ldo, int accumulate, const int* gate) {
+  if (dtype == MGP_F64)
+    return gemm_nt_launch<double>(h, (const double*)P, ldp, m, (const double*)A, lda, n, K, (double*)out, ldo,
+                                  accumulate, gate);
+  return gemm_nt_launch<float>(h, (const float*)P, ldp, m, (const float*)A, lda, n, K, (float*)out, ldo, accumulate,
+                               gate);
+}
+
 int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale) {
   const long tot = n * n;
   if (dtype == MGP_F64)
@@ -558,6 +567,7 @@ extern "C" int mgp_k_dense(mgp_handle* h, const mgp_kernel* k, const void* A, in
                                                    (long)na, (long)nb, (long)ld);
   if (na == 0 || nb == 0) return MGP_OK;
   if (!A || !B || !out) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (k->D > MGP_FUSED_MAX_D) return mgp_k_dense_generic(h, k, A, na, B, nb, out, ld, jitter, diag_add, nullptr);
   if (k->dtype == MGP_F64)
     return k_dense_t<double>(h, k, (const double*)A, na, (const double*)B, nb, (double*)out, ld, jitter,
                              (const double*)diag_add);

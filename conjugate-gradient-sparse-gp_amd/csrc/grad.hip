@@ -109,7 +109,7 @@ template <typename T, int KIND>
 int vjp_dp(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* B, long nb, const T* G, long ldg,
            double* dvar, double* dls) {
   SweepParams prm = mgp_make_params(k);
-  for (int d = 0; d < MGP_MAX_D; ++d) prm.inv_ls[d] = d < k->D ? 1.0 / k->lengthscales[d] : 0.0;
+  for (int d = 0; d < MGP_FUSED_MAX_D; ++d) prm.inv_ls[d] = d < k->D ? 1.0 / k->lengthscales[d] : 0.0;
   const int D = k->D;
   const int DPv = D <= 2 ? 2 : (D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32)));
   const long nbx = (nb + 255) / 256;
@@ -163,6 +163,7 @@ int vjp_t(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* B, l
 extern "C" int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B,
                                int64_t nb, const void* G, int64_t ldg, double* dvariance, double* dlengthscales) {
   MGP_TRY(mgp_check_kernel(h, k));
+  MGP_TRY(mgp_check_fused_dim(h, k, "k_dense_vjp"));
   if (!dvariance || !dlengthscales) return mgp_fail(h, MGP_E_BADARG, "NULL output");
   *dvariance = 0.0;
   for (int d = 0; d < k->D; ++d) dlengthscales[d] = 0.0;

@@ -25,9 +25,13 @@ struct mgp_handle {
   // operator scratch (u = K_nm p and the [Bt,M] partial of the SGPR operator)
   void* opws = nullptr;
   size_t opws_bytes = 0;
+  // generic-D scratch (transposed multipliers, kernel panel, chunk output)
+  void* gen = nullptr;
+  size_t gen_bytes = 0;
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
+  double* dparams = nullptr;  // device copy of c/lengthscale_d for the generic-D kernels [MGP_MAX_D]
   int num_cus = 256;
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
@@ -116,9 +120,16 @@ inline int mgp_check_kernel(mgp_handle* h, const mgp_kernel* k) {
   return MGP_OK;
 }
 
+// entry points without a generic-D form yet
+inline int mgp_check_fused_dim(mgp_handle* h, const mgp_kernel* k, const char* what) {
+  if (k->D > MGP_FUSED_MAX_D)
+    return mgp_fail(h, MGP_E_SHAPE, "%s supports D <= %d (got %d)", what, MGP_FUSED_MAX_D, k->D);
+  return MGP_OK;
+}
+
 // Scaled kernel parameters passed by value to device code.
 struct SweepParams {
-  double inv_ls[MGP_MAX_D];  // c_kind / lengthscale_d
+  double inv_ls[MGP_FUSED_MAX_D];  // c_kind / lengthscale_d (fused kernels only: D <= 32)
   double variance;
   double clamp;  // c_kind^2 * 1e-36
 };
@@ -126,7 +137,7 @@ struct SweepParams {
 inline SweepParams mgp_make_params(const mgp_kernel* k) {
   SweepParams p;
   const double c = mgp_profile_scale(k->kind);
-  for (int d = 0; d < MGP_MAX_D; ++d) p.inv_ls[d] = d < k->D ? c / k->lengthscales[d] : 0.0;
+  for (int d = 0; d < MGP_FUSED_MAX_D; ++d) p.inv_ls[d] = d < k->D ? c / k->lengthscales[d] : 0.0;
   p.variance = k->variance;
   p.clamp = c * c * 1e-36;
   return p;
@@ -151,6 +162,13 @@ inline VecViewMut mgp_view_mut(void* p, int64_t n, int64_t R, int layout) {
 // out(i,r) = variance * sum_j k(a_i, b_j) w(j,r) [+ alpha * addend(i,r)];  gate: device int, skip if 0
 int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
               VecView W, int32_t R, VecViewMut out, double alpha, VecView addend, const int* gate);
+// generic-D forms (generic.hip): explicit panels + NT GEMM, any D <= MGP_MAX_D
+int mgp_k_dense_generic(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
+                        void* out, int64_t ld, double jitter, const void* diag_add, const int* gate);
+int mgp_sweep_generic(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
+                      VecView W, int32_t R, VecViewMut out, double alpha, VecView addend, const int* gate);
+int mgp_gemm_nt(mgp_handle* h, int dtype, const void* P, int64_t ldp, int64_t m, const void* A, int64_t lda, int64_t n,
+                int64_t K, void* out, int64_t ldo, int accumulate, const int* gate);
 int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long na, const double* B, long nb,
                        const double* W, long w_sj, long w_sr, int R, double* out, long o_si, long o_sr,
                        double alpha, const double* addend, long ad_si, long ad_sr, const int* gate);

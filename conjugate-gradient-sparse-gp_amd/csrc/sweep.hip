@@ -418,6 +418,7 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
     // empty sum: out = alpha*addend (or 0); rare path, handled by a 1-chunk sweep over a dummy tile
     return mgp_fail(h, MGP_E_SHAPE, "empty broadcast set");
   }
+  if (k->D > MGP_FUSED_MAX_D) return mgp_sweep_generic(h, k, A, na, B, nb, W, R, out, alpha, addend, gate);
   if (k->dtype == MGP_F64 && h->sweep_mode == 1)
     return mgp_sweep_mfma_f64(h, k, (const double*)A, na, (const double*)B, nb, (const double*)W.base, W.si, W.sr,
                               R, (double*)out.base, out.si, out.sr, alpha, (const double*)addend.base, addend.si,
@@ -435,6 +436,7 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
 extern "C" int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
                                  int64_t M, void* out) {
   MGP_TRY(mgp_check_kernel(h, k));
+  MGP_TRY(mgp_check_fused_dim(h, k, "kmn_sq_colsum"));
   if (N < 0 || M < 0) return mgp_fail(h, MGP_E_SHAPE, "negative size");
   if (M == 0) return MGP_OK;
   if (!Z || !out || (N > 0 && !X)) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");

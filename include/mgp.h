@@ -32,7 +32,10 @@ extern "C" {
 #endif
 
 #define MGP_VERSION 100 /* 0.1.0 */
-#define MGP_MAX_D 32    /* input dimensions supported by the fused sweeps */
+#define MGP_MAX_D 512      /* input dimensions the library accepts (capacity of mgp_kernel) */
+#define MGP_FUSED_MAX_D 32 /* up to here the fused register-resident sweeps run; above, products go through
+                            * row-chunked explicit kernel panels + the NT GEMM (the reference's dense form);
+                            * nearest-centre, the k^2 column sum and the kernel VJP are fused-only for now */
 
 enum { MGP_OK = 0, MGP_E_BADARG = -1, MGP_E_SHAPE = -2, MGP_E_DTYPE = -3, MGP_E_HIP = -4,
        MGP_E_COMM = -5, MGP_E_NOMEM = -6 };

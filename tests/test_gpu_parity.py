@@ -179,6 +179,43 @@ def test_sweep_tiny_lengthscale_takes_the_clamped_path():
     assert relerr(out2, ko2.K(X2, Z2).T @ np.ones((700, 1))) < 1e-11
 
 
+@pytest.mark.parametrize("name", KINDS)
+@pytest.mark.parametrize("D", [33, 40, 90])
+def test_generic_dimension_path(name, D):
+    """D > 32 leaves the fused register-resident sweeps: explicit panels + NT GEMM, same results."""
+    from cggp import kernels as gk, ops
+    from cggp.conjugate_gradient import ConjugateGradient, SgprNormalOperator
+    N, M, R = 700, 90, 3
+    k, ko = make_kernel(name, D)
+    # keep scaled distances O(1) in high dimension so the kernel values are not all ~0
+    for d in range(D):
+        k.lengthscales[d] *= np.sqrt(D)
+    ko.lengthscales = ko.lengthscales * np.sqrt(D)
+    X, Z = points(N, M, D)
+    rng = np.random.default_rng(2)
+    V, W = rng.standard_normal((M, R)), rng.standard_normal((N, R))
+    K = ko.K(X, Z)
+    assert np.max(np.abs(K)) > 1e-3
+    spec = k.spec(D)
+    assert relerr(k.K(T(X), T(Z)), K) < 1e-12
+    # (Matern12 diagonal: the oracle's expansion leaves ~1e-8 noise at coincident points, the
+    # generic path uses direct differences and returns the variance exactly)
+    dtol = 1e-12 if name != "matern12" else 3e-7
+    assert relerr(gk.Kuu(T(Z), k, jitter=1e-3, diag_add=T(np.ones(M))), ko.K(Z) + (1 + 1e-3) * np.eye(M)) < dtol
+    assert relerr(ops.knm_matvec(spec, T(X), T(Z), T(V)), K @ V) < 1e-11
+    assert relerr(ops.kmn_matvec(spec, T(X), T(Z), T(W)), K.T @ W) < 1e-11
+    assert relerr(ops.knm_matvec(spec, T(X), T(Z), T(V.T), ops.ROWS), (K @ V).T) < 1e-11
+    assert relerr(ops.kmn_knm(spec, T(X), T(Z)), K.T @ K) < 1e-11
+    op = SgprNormalOperator(k, T(X), T(Z), 0.1, jitter=1e-6)
+    S = om.SgprNormalOperator(X, Z, ko, 0.1, jitter=1e-6).dense()
+    assert relerr(op.dense(), S) < 1e-9  # matern12 again (Z are not rows of X here, but near-ties exist)
+    rhs = rng.standard_normal((M, 2))
+    sol = ConjugateGradient(1e-14, max_iterations=3000)(op, T(rhs))
+    assert relerr(sol, np.linalg.solve(S, rhs)) < 1e-6
+    with pytest.raises(RuntimeError, match="D <= 32"):
+        ops.nearest_center(spec, T(X), T(Z))
+
+
 # ------------------------------------------------------------------ dense K
 @pytest.mark.parametrize("name", KINDS)
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -655,5 +692,5 @@ def test_errors_are_loud():
     with pytest.raises(TypeError):
         ops.knm_matvec(k.spec(3), T(X), T(Z, torch.float32), T(np.zeros((4, 1))))
     with pytest.raises(ValueError):
-        k.spec(40).struct(1)  # D > MGP_MAX_D
+        k.spec(600).struct(1)  # D > MGP_MAX_D
     assert issubclass(MgpError, RuntimeError)
