@@ -114,7 +114,7 @@ def test_config_c1_end_to_end_against_oracle():
     syn = synthetic.make_inputs(N, D, M, dt)
     X, y, Z = (torch.from_numpy(a).to(dev()) for a in (syn.X, syn.y, syn.Z))
     kern, ko = kernels.SquaredExponential(1.0, [1.0]), ok.Kernel("se", 1.0, np.ones(1))
-    cg, cgo = ConjugateGradient(1e-15, max_iterations=20000), ocg.ConjugateGradient(1e-15, max_iterations=20000)
+    cg, cgo = ConjugateGradient(1e-15, max_iterations=2500), ocg.ConjugateGradient(1e-15, max_iterations=2500)
     # CDGP
     m = CGGP(kern, 0.1, Z, cg, num_probes=None, num_data=N)
     assign_inducing_parameters(m, *oips_update_inducing_parameters(m, (X, y), Z))
