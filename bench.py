@@ -234,7 +234,10 @@ def main():
                        "N": N, "D": D, "M": M, "rhs": 1, "rows_per_gpu": n_local,
                        "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M] per step"},
             "roofline": {
-                "bound": "fp64-valu (the fused sweep is VALU-issue bound, not HBM/MFMA: SURVEY 8d, DESIGN.md)",
+                "bound": "mfma",
+                "bound_note": "fp64 compute roofline: on MI355X the fp64 vector and matrix peaks are the same 78.6 "
+                              "TFLOP/s and share the ALUs; this kernel issues VALU (DESIGN.md 4.1), it is not HBM-bound "
+                              "(SURVEY 8d) -- the hbm figures BASELINE.json asks for are in the nested object",
                 "kernel": "sweep_kernel<double,8,SE,1> (K_nm.p and K_mn.u are the same symbol)",
                 "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS,
