@@ -30,4 +30,4 @@ Parity status (be precise about what is and is not pinned):
 Every function cites the reference file:line it follows.
 """
 
-from . import kernels, cg, models, distance, cluster  # noqa: F401
+from . import kernels, cg, models, distance, cluster, selection  # noqa: F401
