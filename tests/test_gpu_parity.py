@@ -694,3 +694,28 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         k.spec(600).struct(1)  # D > MGP_MAX_D
     assert issubclass(MgpError, RuntimeError)
+
+
+# ------------------------------------------------------------------ row F4: parameter I/O, reports
+def test_parameter_io_and_condition_report(tmp_path):
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import CGGP
+    from cggp.utils import covariance_properties, load_params, multiple_assign, parameter_dict, store_params
+    X, y, Z, k, ko, u, counts = model_problem("matern32")
+    m = CGGP(k, 0.1, T(Z), ConjugateGradient(1e-10), num_probes=None, pseudo_u=T(u), cluster_counts=T(counts))
+    p = parameter_dict(m)
+    assert set(p) == {".kernel.variance", ".kernel.lengthscales", ".likelihood.variance", ".inducing_variable.Z",
+                      ".pseudo_u", ".cluster_counts"}
+    store_params(tmp_path / "params.npz", p)
+    q = load_params(tmp_path / "params.npz")
+    k2, _ = make_kernel("matern32", 2, variance=9.0, seed=5)
+    m2 = CGGP(k2, 0.7, T(Z * 0), ConjugateGradient(1e-10), num_probes=None)
+    multiple_assign(m2, q)
+    a, b = m.predict_f(T(X[:40])), m2.predict_f(T(X[:40]))
+    assert relerr(b[0], a[0].cpu().numpy()) < 1e-12 and relerr(b[1], a[1].cpu().numpy()) < 1e-12
+    rep = covariance_properties(m, jitter=1e-6)
+    ev = np.linalg.eigvalsh(ok.Kuu(Z, ko, 1e-6))
+    assert abs(rep["condition_number"] - ev.max() / ev.min()) / (ev.max() / ev.min()) < 1e-6
+    rep2 = covariance_properties(m, with_lambda=True)
+    ev2 = np.linalg.eigvalsh(ok.Kuu(Z, ko) + np.diag(0.1 / counts[:, 0]))
+    assert abs(rep2["eig_min"] - ev2.min()) < 1e-9 and abs(rep2["eig_max"] - ev2.max()) < 1e-8
