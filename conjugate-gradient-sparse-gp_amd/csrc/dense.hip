@@ -3,10 +3,11 @@
 //   mgp_k_dense      out[na, nb] = k(A, B) (+ jitter, + diag_add)       rows K3, K4
 //   mgp_symm_matmul  out[Bt, n] = P[Bt, n] @ A[n, n], A symmetric       row M2 (`p @ A`)
 //
-// The product has two regimes: Bt <= 8 is a GEMV family (HBM-bound: A is read once,
-// s(n^2 + 2 n Bt) bytes) done with coalesced 16-byte row reads and wavefront reductions;
-// larger Bt is a GEMM on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 128x128 tiles
-// staged through LDS.  fp32 uses v_mfma_f32_16x16x4_f32 with the same tiling.
+// The product has three regimes: Bt = 1 is a GEMV (HBM-bound: A is read once, s(n^2 + 2n)
+// bytes; coalesced 16-byte row reads, wavefront reductions); 2 <= Bt <= 128 keeps that single
+// pass over A and does the Bt-wide contraction on the matrix cores (symm_skinny_kernel); larger
+// Bt is an LDS-tiled NT GEMM on v_mfma_f64_16x16x4_f64 (v_mfma_f32_16x16x4_f32 for fp32), which
+// also serves the K_mn K_nm contraction (contract.hip) and the generic-D products (generic.hip).
 #include <cstdlib>
 
 #include "mgp_common.h"
@@ -98,7 +99,7 @@ int k_dense_t(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* 
   }
 }
 
-// ------------------------------------------------------------------ GEMV family (Bt <= 8)
+// ------------------------------------------------------------------ GEMV (one right-hand side)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A,
     }
 }
 
-// ------------------------------------------------------------------ MFMA GEMM (Bt > 8)
+// ------------------------------------------------------------------ MFMA GEMM
 template <typename T>
 struct Mfma;
 template <>
@@ -384,31 +385,46 @@ __global__ __launch_bounds__(512) void symm_skinny_kernel(const T* __restrict__ 
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
   const bool vec = (n & 3) == 0;
-  for (long k0 = (long)wave * 16; k0 < n; k0 += 8 * 16) {
+  // software pipeline: the operands of slab k+1 are in flight while slab k runs on the matrix core
+  T a[4], an[4];
+  T p[NBT][4], pn[NBT][4];
+  auto load_slab = [&](long k0, T (&av)[4], T (&pv)[NBT][4]) {
     const long kb = k0 + 4 * g;
-    T a[4];
     if (vec && kb + 3 < n) {
       using V4 = __attribute__((ext_vector_type(4))) T;
       const V4 v = *reinterpret_cast<const V4*>(arow + kb);
-      a[0] = v[0];
-      a[1] = v[1];
-      a[2] = v[2];
-      a[3] = v[3];
+      av[0] = v[0];
+      av[1] = v[1];
+      av[2] = v[2];
+      av[3] = v[3];
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = kb + s < n ? arow[kb + s] : (T)0;
+      for (int s = 0; s < 4; ++s) av[s] = kb + s < n ? arow[kb + s] : (T)0;
     }
-    T p[NBT][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const long k = kb + s;
 #pragma unroll
-      for (int bt = 0; bt < NBT; ++bt) p[bt][s] = k < n ? Pt[k * BP + bt * 16 + jj] : (T)0;
+      for (int bt = 0; bt < NBT; ++bt) pv[bt][s] = k < n ? Pt[k * BP + bt * 16 + jj] : (T)0;
     }
+  };
+  long k0 = (long)wave * 16;
+  if (k0 < n) load_slab(k0, a, p);
+  for (; k0 < n; k0 += 8 * 16) {
+    const long kn = k0 + 8 * 16;
+    if (kn < n) load_slab(kn, an, pn);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(p[bt][s], a[s], acc[bt]);
+    if (kn < n) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = an[s];
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) p[bt][s] = pn[bt][s];
+      }
+    }
   }
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt)
@@ -463,10 +479,7 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
       hipLaunchKernelGGL((symm_gemv_kernel<T, BTV, 1>), grid, dim3(256), 0, h->stream, A, n, P, (int)Bt, out,    \
                          gate, 0L, n, (T)1, 0);                                                                 \
   } while (0)
-  if (Bt == 1) MGP_GV(1);
-  else if (Bt == 2) MGP_GV(2);
-  else if (Bt <= 4) MGP_GV(4);
-  else MGP_GV(8);
+  MGP_GV(1);  // Bt == 1 here: 2..128 took the skinny path, larger the GEMM
 #undef MGP_GV
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;
