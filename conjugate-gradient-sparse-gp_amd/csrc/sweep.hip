@@ -155,13 +155,6 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
     const bool safe = (T)2 * (aa + bb) < (T)524288;  // NaN inputs compare false -> clamped loop
 
     auto body = [&](auto e2) {
-      T a2l[RPT];
-      double fb[RPT];  // FAST: 2^(-rho) so that the common 2^rho epilogue stays valid
-#pragma unroll
-      for (int q = 0; q < RPT; ++q) {
-        a2l[q] = FAST ? norm2(q) : a2[FAST ? 0 : q];
-        fb[q] = FAST ? mgp_exp2(-(((double)MGP_EXP2_MAGIC - cq[FAST ? q : 0]) - (double)a2l[q])) : 1.0;
-      }
 #pragma unroll UJ
       for (int jj = 0; jj < TB; ++jj) {
         const T* p = &tile[jj * PS];
@@ -174,12 +167,16 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
         for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-          T s = nb2 - a2l[q];
+          // FAST kernels reach this loop only for tiles that fail the distance bound (rare): a2 and
+          // the 2^(-rho) factor that keeps the common 2^rho epilogue valid are recomputed per pair
+          // rather than held in registers across the whole sweep
+          const T a2q = FAST ? norm2(q) : a2[FAST ? 0 : q];
+          T s = nb2 - a2q;
 #pragma unroll
           for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
           T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
           if (SQ) kv = kv * kv;
-          if (FAST) kv = (T)((double)kv * fb[q]);
+          if (FAST) kv = (T)((double)kv * mgp_exp2(-(((double)MGP_EXP2_MAGIC - cq[FAST ? q : 0]) - (double)a2q)));
 #pragma unroll
           for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
         }
