@@ -50,7 +50,15 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--convergence-cap", type=int, default=0, help="iteration cap of the convergence leg (0 = M)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: run the all-reduce hook on a 1-rank group (measures its fixed per-step cost)")
+    ap.add_argument("--rows", type=int, default=0, help="override the TOTAL row count (0 = the config's)")
     args = ap.parse_args()
+
+    # Only the JSON line may reach stdout (RCCL prints a version banner there): park fd 1 on stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -63,8 +71,11 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -74,6 +85,8 @@ def main():
     from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
 
     N, D, M, dtype_name, kname = synthetic.CONFIGS[args.config]
+    if args.rows:
+        N = args.rows
     tdtype = torch.float64 if dtype_name == "float64" else torch.float32
     esize = 8 if dtype_name == "float64" else 4
     syn = synthetic.make_inputs(N, D, M, dtype_name)
@@ -85,7 +98,7 @@ def main():
     kern = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname](
         variance=syn.variance, lengthscales=syn.lengthscales)
     spec = kern.spec(D)
-    allreduce = parallel.make_allreduce()
+    allreduce = parallel.make_allreduce(force=args.force_collective)
     op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1,
                             kmm_rows=parallel.kmm_slab(M))
     rhs = ops.kmn_matvec(spec, X, Z, y)  # K_mn y  [M,1]
@@ -257,7 +270,10 @@ def main():
             "convergence": conv,
             "cdgp_same_size": cdgp,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,14 +27,14 @@ def shard_rows(t, world_size=None, rank=None):
     return t[lo:hi]
 
 
-def make_allreduce(group=None):
+def make_allreduce(group=None, force=False):
     """In-place sum over ranks of a flat tensor view; None when there is a single rank.
 
     The tensor is a view of a buffer the caller owns (libmgp hands the partial product to the
     collective through `SgprNormalOperator`'s buffer), the call is enqueued behind the kernels
     already on torch's current stream.
     """
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return None
 
     host_staged = dist.get_backend(group) == "gloo"
