@@ -65,6 +65,72 @@ def eval_logdet(matrix, cg, num_probes=None, probes=None):
     return _EvalLogdet.apply(matrix, cg, num_probes, probes)
 
 
+class LpSVGP:
+    """`cggp/models.py:51-173` (Panos et al. SVGP with diagonal q-covariance): parameters `nu [M,1]`
+    and `diag_variance [M,1]`; Cholesky solves on the [M,M] matrix libmgp builds.  The base of the
+    reference's class tree; `ClusterGP` replaces `nu`/`diag_variance` by pseudo_u and sigma^2/counts."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps=1, nu=None,
+                 diag_variance=None, num_data=None):
+        assert num_latent_gps == 1, "One latent GP is allowed"  # :76
+        self.kernel = kernel
+        self.likelihood = likelihood if not isinstance(likelihood, (int, float)) else Gaussian(likelihood)
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)
+        self.mean_function = mean_function
+        self.num_data = num_data
+        Z = self.inducing_variable.Z
+        shape = (Z.shape[0], 1)
+        self.nu = (torch.zeros(shape, dtype=Z.dtype, device=Z.device) if nu is None  # :93
+                   else torch.as_tensor(nu, dtype=Z.dtype, device=Z.device).reshape(shape).clone())
+        self.diag_variance = (torch.full(shape, 1e-4, dtype=Z.dtype, device=Z.device) if diag_variance is None  # :94
+                              else torch.as_tensor(diag_variance, dtype=Z.dtype, device=Z.device).reshape(shape).clone())
+
+    def _mean(self, Xnew):
+        return 0.0 if self.mean_function is None else self.mean_function(Xnew)
+
+    def _K(self):
+        Kmm = Kuu(self.inducing_variable, self.kernel, jitter=0.0)  # :112 / :141
+        return Kmm, Kuu(self.inducing_variable, self.kernel, jitter=0.0, diag_add=self.diag_variance[:, 0])
+
+    def prior_kl(self):  # :107-120
+        Kmm, K = self._K()
+        nut = self.nu.t().contiguous()
+        quad = ops.dot_all(ops.symm_matmul(Kmm, nut), nut)
+        L = torch.linalg.cholesky(K)
+        trace = torch.cholesky_solve(Kmm, L).diagonal().sum().item()
+        logdet = (2.0 * torch.log(L.diagonal())).sum().item() - torch.log(self.diag_variance).sum().item()
+        return 0.5 * (quad - trace + logdet)
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):  # :136-161
+        assert not full_output_cov
+        _, K = self._K()
+        Kmn = Kuf(self.inducing_variable, self.kernel, Xnew)
+        L = torch.linalg.cholesky(K)
+        A = torch.linalg.solve_triangular(L, Kmn, upper=False)
+        if not full_cov:
+            fvar = (self.kernel.K_diag(Xnew) - ops.colwise_dot(A, A))[:, None]
+        else:
+            fvar = (self.kernel.K(Xnew) - A.t() @ A)[None, ...]
+        fmu = ops.knm_matvec(self.kernel.spec(Xnew.shape[1]), Xnew, self.inducing_variable.Z, self.nu)  # :157
+        return fmu + self._mean(Xnew), fvar
+
+    def scale(self, batch_size, dtype=None):  # :163-169
+        return 1.0 if self.num_data is None else float(self.num_data) / float(batch_size)
+
+    def elbo(self, data):  # :125-134
+        x, y = data
+        kl = self.prior_kl()
+        f_mean, f_var = self.predict_f(x)
+        var_exp = self.likelihood.variational_expectations(x, f_mean, f_var, y)
+        return var_exp.sum().item() * self.scale(x.shape[0]) - kl
+
+    def maximum_log_likelihood_objective(self, data):  # :122-123
+        return self.elbo(data)
+
+    def q_moments(self, full_cov=False):  # :171-173
+        return self.predict_f(self.inducing_variable.Z, full_cov=full_cov)
+
+
 class ClusterGP:
     """Cluster-data GP with Cholesky solves (`cggp/models.py:176-276`); parameter container of
     row M6.  The Cholesky factorisation itself is a plain library call (torch.linalg) on the

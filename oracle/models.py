@@ -68,6 +68,46 @@ def eval_logdet_grad(matrix, cg, df=1.0, num_probes=None, probes=None):
     return (lv @ rv.T) / dtype.type(P)  # :42
 
 
+# ---------------------------------------------------------------- LpSVGP
+class LpSVGP:
+    """`cggp/models.py:51-173`: q-mean `Kmn^T nu`, diagonal `diag_variance`, Cholesky solves."""
+
+    def __init__(self, kernel, noise_variance, Z, nu=None, diag_variance=None, num_data=None):
+        self.kernel, dt = kernel, kernel.dtype
+        self.noise_variance = dt.type(noise_variance)
+        self.Z = np.asarray(Z, dtype=dt)
+        M = self.Z.shape[0]
+        self.nu = np.zeros((M, 1), dt) if nu is None else np.asarray(nu, dt).reshape(M, 1)  # :93
+        self.diag_variance = (np.full((M, 1), 1e-4, dt) if diag_variance is None  # :94
+                              else np.asarray(diag_variance, dt).reshape(M, 1))
+        self.num_data = num_data
+
+    def prior_kl(self):  # :107-120
+        Kmm = Kuu(self.Z, self.kernel, jitter=0.0)
+        quad = np.sum(self.nu * (Kmm @ self.nu))
+        K = add_diagonal(Kmm, self.diag_variance[:, 0])
+        L = np.linalg.cholesky(K)
+        trace = np.trace(np.linalg.solve(L.T, np.linalg.solve(L, Kmm)))
+        logdet = np.sum(2.0 * np.log(np.diag(L))) - np.sum(np.log(self.diag_variance))
+        return 0.5 * (quad - trace + logdet)
+
+    def predict_f(self, Xnew, full_cov=False):  # :136-161
+        Kmm = Kuu(self.Z, self.kernel, jitter=0.0)
+        Kmn = Kuf(self.Z, self.kernel, Xnew)
+        Knn = self.kernel.K(Xnew) if full_cov else self.kernel.K_diag(Xnew)
+        L = np.linalg.cholesky(add_diagonal(Kmm, self.diag_variance[:, 0]))
+        A = np.linalg.solve(L, Kmn)
+        fvar = (Knn - A.T @ A)[None, ...] if full_cov else (Knn - np.sum(np.square(A), axis=0))[:, None]
+        return Kmn.T @ self.nu, fvar
+
+    def elbo(self, data):  # :125-134
+        x, y = data
+        f_mean, f_var = self.predict_f(x)
+        ve = gaussian_variational_expectations(f_mean, f_var, y, self.noise_variance)
+        scale = 1.0 if self.num_data is None else self.num_data / x.shape[0]
+        return np.sum(ve) * scale - self.prior_kl()
+
+
 # ---------------------------------------------------------------- ClusterGP / CGGP
 class ClusterGP:
     """Cholesky twin (`cggp/models.py:176-276`) -- a second oracle for CGGP."""

@@ -719,3 +719,22 @@ def test_parameter_io_and_condition_report(tmp_path):
     rep2 = covariance_properties(m, with_lambda=True)
     ev2 = np.linalg.eigvalsh(ok.Kuu(Z, ko) + np.diag(0.1 / counts[:, 0]))
     assert abs(rep2["eig_min"] - ev2.min()) < 1e-9 and abs(rep2["eig_max"] - ev2.max()) < 1e-8
+
+
+def test_lpsvgp_base_class():
+    """`cggp/models.py:51-173`: the base of the reference's class tree (free nu and diag_variance)."""
+    from cggp.models import LpSVGP
+    X, y, Z, k, ko, u, counts = model_problem("matern52")
+    rng = np.random.default_rng(0)
+    nu, dv = rng.standard_normal((40, 1)), rng.random((40, 1)) + 0.05
+    m = LpSVGP(k, 0.2, T(Z), nu=T(nu), diag_variance=T(dv), num_data=600)
+    r = om.LpSVGP(ko, 0.2, Z, nu=nu, diag_variance=dv, num_data=600)
+    mu, var = m.predict_f(T(X[:77]))
+    mu0, var0 = r.predict_f(X[:77])
+    assert relerr(mu, mu0) < 1e-10 and relerr(var, var0) < 1e-9
+    assert relerr(m.predict_f(T(X[:5]), full_cov=True)[1], r.predict_f(X[:5], full_cov=True)[1]) < 1e-9
+    assert abs(m.prior_kl() - r.prior_kl()) / abs(r.prior_kl()) < 1e-9
+    e, e0 = m.elbo((T(X[:100]), T(y[:100]))), r.elbo((X[:100], y[:100]))
+    assert abs(e - e0) / abs(e0) < 1e-9
+    d = LpSVGP(k, 0.2, T(Z))  # defaults: nu = 0, diag_variance = 1e-4 (:93-94)
+    assert float(d.nu.abs().max()) == 0.0 and float((d.diag_variance - 1e-4).abs().max()) == 0.0
