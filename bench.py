@@ -177,6 +177,30 @@ def main():
                 "seconds": time.perf_counter() - tc,
                 "note": "absolute criterion 0.5||r||^2 <= 1e-6 of the reference, no preconditioner"}
 
+    # ---- the same solve with the subsampled normal-equation preconditioner (build-side addition,
+    # DESIGN.md 4.6): P = s2 Kmm + (N/n_s) Ks^T Ks from n_s = 16 M sampled rows, z = r @ P^-1
+    pcg = None
+    try:
+        from cggp.conjugate_gradient import SubsampledNormalPreconditioner
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=16, seed=0)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - tb
+        tc = time.perf_counter()
+        sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, pre, max_iterations=M,
+                                               max_steps_cycle=M + 1, check_every=8)
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - tc
+        rres = rhs_rows - op.rmatmul(sol)
+        pcg = {"preconditioner": "SubsampledNormalPreconditioner(rows_per_inducing=16)",
+               "sample_rows": pre.sample_rows, "build_seconds": t_build, "error_threshold": 1e-6,
+               "iterations": int(steps), "converged": bool(int(steps) < M), "solve_seconds": t_solve,
+               "half_rz_final": float(err.max().item()),
+               "true_half_residual_sq": 0.5 * float((rres * rres).sum().item())}
+    except Exception as e:
+        pcg = {"error": repr(e)}
+
     # ---- CDGP leg at the same size (informational; SURVEY §8e: no per-iteration collective):
     # assignment + cluster statistics over the local rows, one [2,M] all-reduce, then the M x M
     # system (Kmm + Lambda) a = u solved by the device CG with the reference's stopping rule
@@ -268,6 +292,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "convergence": conv,
+            "convergence_preconditioned": pcg,
             "cdgp_same_size": cdgp,
         }
         sys.stdout.flush()

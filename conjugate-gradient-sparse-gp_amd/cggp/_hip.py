@@ -16,7 +16,7 @@ MGP_FUSED_MAX_D = 32
 F32, F64 = 0, 1
 SE, MATERN12, MATERN32, MATERN52 = 0, 1, 2, 3
 COLS, ROWS = 0, 1
-PRE_EYE, PRE_JACOBI, PRE_BLOCK = 0, 1, 2
+PRE_EYE, PRE_JACOBI, PRE_BLOCK, PRE_DENSE = 0, 1, 2, 3
 OP_DENSE, OP_SGPR, OP_KMM_LAMBDA = 0, 1, 2
 
 KERNEL_KINDS = {"se": SE, "matern12": MATERN12, "matern32": MATERN32, "matern52": MATERN52}
@@ -71,6 +71,7 @@ class MgpPrecond(ctypes.Structure):
         ("diag_inv", ctypes.c_void_p),
         ("block_index", ctypes.c_void_p),
         ("block_inv", ctypes.c_void_p),
+        ("dense_inv", ctypes.c_void_p),
     ]
 
 

@@ -104,33 +104,42 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const T* __restrict__ b, c
   }
 }
 
-// mode 0: full step.  mode 1: first half only (gamma, v, no r update: refresh follows).
-// mode 2: second half after a refresh (r already = b - v@A): z, rz, p = z, flags.
+// Generic step pieces (refresh steps, block / dense preconditioners).  Modes:
+//   0  first half (gamma, v, r -= gamma Ap) + native preconditioner + second half
+//   1  first half without the r update (a residual refresh follows)
+//   2  native preconditioner + second half with beta = 0 (after a refresh: p = z)
+//   3  first half only, with the r update (a dense preconditioner product follows)
+//   4  second half with z already in memory (dense preconditioner), normal beta
+//   5  second half with z already in memory, beta = 0 (start-up and refresh: p = z)
+// `force` bypasses the gate (start-up of the dense-preconditioner path).
 template <typename T>
 __global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
                                                         T* __restrict__ r, T* __restrict__ p,
                                                         T* __restrict__ z, const T* __restrict__ ap,
                                                         T* __restrict__ rz, int* __restrict__ over,
                                                         T* __restrict__ err, long n, T thr, T min_float,
-                                                        PrecondDev pc, int mode) {
-  if (ctrl->active == 0) return;
+                                                        PrecondDev pc, int mode, int force) {
+  if (!force && ctrl->active == 0) return;
   __shared__ T red[8];
   const long off = (long)blockIdx.x * n;
   const T rz_old = rz[blockIdx.x];
-  if (mode != 2) {
+  const bool first = mode == 0 || mode == 1 || mode == 3;
+  if (first) {
     T d = 0;
     for (long j = threadIdx.x; j < n; j += blockDim.x) d = mgp_fma(p[off + j], ap[off + j], d);
     d = block_sum(d, red);
     const T gamma = (d <= min_float) ? (T)0 : rz_old / d;
     for (long j = threadIdx.x; j < n; j += blockDim.x) {
       v[off + j] = mgp_fma(gamma, p[off + j], v[off + j]);
-      if (mode == 0) r[off + j] = mgp_fma(-gamma, ap[off + j], r[off + j]);
+      if (mode != 1) r[off + j] = mgp_fma(-gamma, ap[off + j], r[off + j]);
     }
-    if (mode == 1) return;
+    if (mode != 0) return;
     __syncthreads();
   }
   const T* zz = r + off;
-  if (pc.kind != MGP_PRE_EYE) {
+  if (mode >= 4) {
+    zz = z + off;  // computed by the dense preconditioner product
+  } else if (pc.kind != MGP_PRE_EYE) {
     apply_precond<T>(pc, r + off, z + off, n);
     zz = z + off;
   }
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict
   }
   s_rz = block_sum(s_rz, red);
   s_rr = block_sum(s_rr, red);
-  const T beta = (mode == 2 || rz_old <= min_float) ? (T)0 : s_rz / rz_old;
+  const T beta = (mode == 2 || mode == 5 || rz_old <= min_float) ? (T)0 : s_rz / rz_old;
   for (long j = threadIdx.x; j < n; j += blockDim.x) p[off + j] = mgp_fma(beta, p[off + j], zz[j]);
   if (threadIdx.x == 0) {
     rz[blockIdx.x] = s_rz;
@@ -260,10 +269,10 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void cg_residual_kernel(const CgCtrl* __restrict__ ctrl,
                                                           const T* __restrict__ b, const T* __restrict__ av,
-                                                          T* __restrict__ r, long total) {
-  if (ctrl->active == 0) return;
+                                                          T* __restrict__ r, long total, int force) {
+  if (!force && ctrl->active == 0) return;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) r[i] = b[i] - av[i];
+  if (i < total) r[i] = av ? b[i] - av[i] : b[i];
 }
 
 __global__ void cg_advance_kernel(CgCtrl* ctrl, const int* __restrict__ over, long Bt, int inc, int max_it) {
@@ -397,6 +406,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   const long tot = Bt * n;
   const auto t0 = std::chrono::steady_clock::now();
   PrecondDev pc{MGP_PRE_EYE, 0, 0, nullptr, nullptr, nullptr};
+  const void* dense_inv = nullptr;  // MGP_PRE_DENSE: z = r @ Pinv through the symmetric product kernels
   if (pre) {
     pc.kind = pre->kind;
     if (pre->kind == MGP_PRE_JACOBI) {
@@ -409,11 +419,16 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
       pc.nb = pre->num_blocks;
       pc.block_index = (const long*)pre->block_index;
       pc.block_inv = pre->block_inv;
+    } else if (pre->kind == MGP_PRE_DENSE) {
+      if (!pre->dense_inv) return mgp_fail(h, MGP_E_BADARG, "dense preconditioner without matrix");
+      dense_inv = pre->dense_inv;
     } else if (pre->kind != MGP_PRE_EYE) {
       return mgp_fail(h, MGP_E_BADARG, "unknown preconditioner kind %d", pre->kind);
     }
   }
-  const bool need_z = pc.kind != MGP_PRE_EYE;
+  const bool dense_pre = dense_inv != nullptr;
+  const bool need_z = pc.kind != MGP_PRE_EYE;  // dense included: z = r @ Pinv lives in memory
+  if (dense_pre) pc.kind = MGP_PRE_EYE;        // the update kernels never apply it themselves
   // arena: r, p, ap, [z], rz[Bt], over[Bt] (int), ctrl
   size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64;
   MGP_TRY(mgp_reserve(h, &h->cg, &h->cg_bytes, bytes));
@@ -435,16 +450,25 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   } else {
     MGP_HIP(h, hipMemsetAsync(V, 0, (size_t)tot * sizeof(T), s));
   }
-  hipLaunchKernelGGL((cg_init_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, B, av, r, z, p, rz, over, err_out, n,
-                     (T)thr, pc);
-  MGP_LAUNCH_CHECK(h);
+  if (!dense_pre) {
+    hipLaunchKernelGGL((cg_init_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, B, av, r, z, p, rz, over, err_out,
+                       n, (T)thr, pc);
+    MGP_LAUNCH_CHECK(h);
+  } else {  // r = b - vA ; z = r @ Pinv ; p = z, rz = z.r, flags
+    hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, av, r, tot, 1);
+    MGP_LAUNCH_CHECK(h);
+    MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, nullptr));
+    hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz, over,
+                       err_out, n, (T)thr, (T)min_float, pc, 5, 1);
+    MGP_LAUNCH_CHECK(h);
+  }
   hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 0, (int)max_it);
   MGP_LAUNCH_CHECK(h);
 
   // fused step kernel: elements of one RHS in registers.  Code = EPT for 256 threads (n <= 1024),
   // 14/12/24/8 for 1024 threads with EPT 1/2/4/8 (n <= 8192); 0 = generic loop kernels.
   int fused_ept = 0;
-  if (pc.kind != MGP_PRE_BLOCK && Bt < 2147483647L) {
+  if (pc.kind != MGP_PRE_BLOCK && !dense_pre && Bt < 2147483647L) {
     if (n <= 256) fused_ept = 1;
     else if (n <= 512) fused_ept = 2;
     else if (n <= 1024) fused_ept = 14;
@@ -483,17 +507,27 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
         MGP_LAUNCH_CHECK(h);
         continue;  // bookkeeping done inside the kernel
       } else if (!reset) {
-        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
-                           over, err_out, n, (T)thr, (T)min_float, pc, 0);
+        if (!dense_pre) {
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                             over, err_out, n, (T)thr, (T)min_float, pc, 0, 0);
+        } else {
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                             over, err_out, n, (T)thr, (T)min_float, pc, 3, 0);
+          MGP_LAUNCH_CHECK(h);
+          MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, &ctrl->active));
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+                             over, err_out, n, (T)thr, (T)min_float, pc, 4, 0);
+        }
       } else {
         hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
-                           over, err_out, n, (T)thr, (T)min_float, pc, 1);
+                           over, err_out, n, (T)thr, (T)min_float, pc, 1, 0);
         MGP_LAUNCH_CHECK(h);
         MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, &ctrl->active));
-        hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot);
+        hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot, 0);
         MGP_LAUNCH_CHECK(h);
+        if (dense_pre) MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, &ctrl->active));
         hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
-                           over, err_out, n, (T)thr, (T)min_float, pc, 2);
+                           over, err_out, n, (T)thr, (T)min_float, pc, dense_pre ? 5 : 2, 0);
       }
       MGP_LAUNCH_CHECK(h);
       hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 1, (int)max_it);

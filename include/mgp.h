@@ -51,7 +51,7 @@ enum { MGP_SE = 0, MGP_MATERN12 = 1, MGP_MATERN32 = 2, MGP_MATERN52 = 3 };
  * function-level layout of conjugate_gradient(), conjugate_gradient.py:24-32). */
 enum { MGP_COLS = 0, MGP_ROWS = 1 };
 
-enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2 };
+enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2, MGP_PRE_DENSE = 3 };
 
 enum { MGP_OP_DENSE = 0, MGP_OP_SGPR = 1, MGP_OP_KMM_LAMBDA = 2 };
 
@@ -107,6 +107,7 @@ typedef struct {
   const void* diag_inv;       /* MGP_PRE_JACOBI: 1/diag(A) [n] device */
   const int64_t* block_index; /* MGP_PRE_BLOCK: [nb, bs] int64 device */
   const void* block_inv;      /* MGP_PRE_BLOCK: inverse of A[idx,idx], [nb, bs, bs] device */
+  const void* dense_inv;      /* MGP_PRE_DENSE: symmetric P^-1 [n, n] device; z = r @ P^-1 */
 } mgp_precond;
 
 typedef struct {

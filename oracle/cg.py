@@ -48,6 +48,18 @@ class BlockPreconditioner:
         return z, np.sum(z * vec, axis=-1, keepdims=True)
 
 
+class DensePreconditioner:
+    """Build-side addition (not in the reference): z = vec @ Pinv for a symmetric positive
+    definite Pinv [n, n] (e.g. the inverse of a cheap approximation of A)."""
+
+    def __init__(self, inverse):
+        self.inverse = np.asarray(inverse)
+
+    def __call__(self, vec, mat):
+        z = vec @ self.inverse
+        return z, np.sum(z * vec, axis=-1, keepdims=True)
+
+
 def _matmul_right(p, A):
     """`state.p @ A` (`conjugate_gradient.py:65`); A may be an operator with .rmatmul."""
     if hasattr(A, "rmatmul"):

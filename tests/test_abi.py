@@ -45,7 +45,7 @@ def test_version_arch_and_struct_layout(lib):
     # struct sizes the C side compiles to (LP64): keeps the ctypes mirror honest
     assert ctypes.sizeof(_hip.MgpKernel) == 4 * 4 + 8 + 8 * _hip.MGP_MAX_D
     assert ctypes.sizeof(_hip.MgpOperator) == 8 + 8 + 8 * 14
-    assert ctypes.sizeof(_hip.MgpPrecond) == 8 + 8 + 8 * 3
+    assert ctypes.sizeof(_hip.MgpPrecond) == 8 + 8 + 8 * 4
     assert ctypes.sizeof(_hip.MgpCgStats) == 16
 
 

@@ -432,12 +432,18 @@ def test_cg_guard_floor_matches_oracle():
     assert float(err.max()) < 1e-15
 
 
-@pytest.mark.parametrize("pre", ["jacobi", "block"])
+@pytest.mark.parametrize("pre", ["jacobi", "block", "dense"])
 def test_cg_preconditioners(pre):
-    from cggp.conjugate_gradient import BlockPreconditioner, ConjugateGradient, JacobiPreconditioner
+    from cggp.conjugate_gradient import (BlockPreconditioner, ConjugateGradient, DensePreconditioner,
+                                         JacobiPreconditioner)
     A, rhs = cg_problem(n=64, noise=0.1)
     if pre == "jacobi":
         P, Po = JacobiPreconditioner(), ocg.JacobiPreconditioner()
+    elif pre == "dense":
+        E = np.random.default_rng(5).standard_normal((64, 8))
+        Pinv = np.linalg.inv(A + 0.05 * E @ E.T)
+        Pinv = 0.5 * (Pinv + Pinv.T)
+        P, Po = DensePreconditioner(T(Pinv)), ocg.DensePreconditioner(Pinv)
     else:
         blocks = np.arange(64).reshape(8, 8)
         P, Po = BlockPreconditioner(blocks), ocg.BlockPreconditioner(blocks)
@@ -448,6 +454,60 @@ def test_cg_preconditioners(pre):
     z, rz = P(T(rhs.T), T(A))
     zo, rzo = Po(rhs.T, A)
     assert relerr(z, zo) < 1e-10 and relerr(rz, rzo) < 1e-10
+
+
+@pytest.mark.parametrize("n,bt,cycle", [(64, 1, 100), (200, 5, 7), (333, 130, 100)])
+def test_cg_dense_preconditioner_steps(n, bt, cycle):
+    """Fixed-iteration parity of the dense-preconditioned loop (start-up, step and refresh paths,
+    GEMV / skinny / GEMM regimes of the z = r @ Pinv product)."""
+    from cggp.conjugate_gradient import DensePreconditioner, conjugate_gradient
+    rng = np.random.default_rng(n)
+    A, _ = cg_problem(n=n, noise=0.1)
+    rhs = rng.standard_normal((bt, n))
+    E = rng.standard_normal((n, n // 4))
+    Pinv = np.linalg.inv(A + 0.2 * E @ E.T / n)
+    Pinv = 0.5 * (Pinv + Pinv.T)
+    v0 = 0.1 * rng.standard_normal((bt, n))
+    for k in (1, 3, 9):
+        sol, (steps, err) = conjugate_gradient(T(A), T(rhs), T(v0), 0.0, DensePreconditioner(T(Pinv)),
+                                               max_iterations=k, max_steps_cycle=cycle)
+        o_sol, (o_steps, o_err) = ocg.conjugate_gradient(A, rhs, v0, 0.0, ocg.DensePreconditioner(Pinv),
+                                                         max_iterations=k, max_steps_cycle=cycle)
+        assert int(steps) == o_steps == k
+        assert relerr(sol, o_sol) < 1e-9, (k, relerr(sol, o_sol))
+        assert relerr(err, o_err) < 1e-6
+
+
+def test_sgpr_subsampled_preconditioner():
+    """PCG on the SGPR normal system: same solution as the closed form, far fewer steps than Eye."""
+    from cggp.conjugate_gradient import ConjugateGradient, SgprNormalOperator, SubsampledNormalPreconditioner
+    from cggp import kernels as ck
+    rng = np.random.default_rng(11)
+    N, M, D = 6000, 128, 3
+    X = rng.uniform(-2, 2, (N, D))
+    Z = X[rng.choice(N, M, replace=False)].copy()
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    kern = ck.SquaredExponential(variance=1.3, lengthscales=[0.9, 1.1, 0.8])
+    okern = ok.Kernel("se", 1.3, np.array([0.9, 1.1, 0.8]))
+    s2 = 0.05
+    op = SgprNormalOperator(kern, T(X), T(Z), s2, jitter=1e-6)
+    Kmn = okern.K(Z, X)
+    S = s2 * (okern.K(Z, Z) + 1e-6 * np.eye(M)) + Kmn @ Kmn.T
+    b = Kmn @ y
+    ref = np.linalg.solve(S, b)
+    P = SubsampledNormalPreconditioner(op, rows_per_inducing=16, seed=0)
+    assert P.sample_rows == 16 * M
+    sol, (steps, err) = ConjugateGradient(1e-10, preconditioner=P, max_iterations=400).solve_with_stats(op, T(b))
+    _, (steps_eye, err_eye) = ConjugateGradient(1e-10, max_iterations=400).solve_with_stats(op, T(b))
+    assert float(err.max()) <= 1e-10 * 10 and int(steps) < 60
+    assert int(steps) * 3 < int(steps_eye)
+    # residual-level agreement with the closed form (S is ill conditioned: compare S sol with b)
+    assert np.max(np.abs(S @ sol.cpu().numpy() - b)) < 1e-3 * np.max(np.abs(b)) * 1e-2
+    # and against the oracle's PCG with the very same P^-1
+    o_sol, (o_steps, _) = ocg.ConjugateGradient(1e-10, preconditioner=ocg.DensePreconditioner(
+        P.inverse.cpu().numpy()), max_iterations=400).solve_with_stats(S, b)
+    assert abs(int(steps) - o_steps) <= 3
+    assert np.max(np.abs(S @ (sol.cpu().numpy() - o_sol))) < 1e-4 * np.max(np.abs(b)) * 1e-2
 
 
 def test_cg_fp32():

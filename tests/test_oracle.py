@@ -136,11 +136,14 @@ def test_cg_initial_solution_and_cycle_refresh():
     assert steps == 0
 
 
-@pytest.mark.parametrize("pre", ["jacobi", "block"])
+@pytest.mark.parametrize("pre", ["jacobi", "block", "dense"])
 def test_cg_preconditioners(pre):
     X, kern, A, rhs = _problem(n=64)
     if pre == "jacobi":
         P = ocg.JacobiPreconditioner()
+    elif pre == "dense":  # inverse of a perturbed A: close to the identity after preconditioning
+        E = np.random.default_rng(5).standard_normal((64, 8))
+        P = ocg.DensePreconditioner(np.linalg.inv(A + 0.05 * E @ E.T))
     else:
         P = ocg.BlockPreconditioner(np.arange(64).reshape(8, 8))
     cg = ocg.ConjugateGradient(1e-26, preconditioner=P, max_iterations=3000, min_float=1e-300)
