@@ -106,6 +106,15 @@ SIGNATURES = {
     "mgp_k_dense_vjp": (_I, [_P, _KP, _P, _L, _P, _L, _P, _L, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),
+    # host-only entry points (cover tree, row F3)
+    "mgp_host_last_error": (ctypes.c_char_p, []),
+    "mgp_covertree_build": (_I, [_P, _L, _I, _D, _I, _I, _I, ctypes.POINTER(_P)]),
+    "mgp_covertree_destroy": (None, [_P]),
+    "mgp_covertree_num_levels": (_I, [_P]),
+    "mgp_covertree_level_size": (_L, [_P, _I]),
+    "mgp_covertree_level_radius": (_D, [_P, _I]),
+    "mgp_covertree_level_nodes": (_I, [_P, _I, _P, _P, _P]),
+    "mgp_covertree_level_rows": (_I, [_P, _I, _P, _P]),
 }
 
 

@@ -6,6 +6,7 @@ search and the per-cluster sums run fused in libmgp; with row-sharded data the [
 counts are summed over ranks by one all-reduce.
 """
 
+import numpy as np
 import torch
 
 from . import ops
@@ -22,6 +23,19 @@ def nearest_centre_statistics(kernel, Z, data, distance_type="sqeuclidean", allr
         allreduce(both.view(-1))
         sums, counts = both[0], both[1]
     return idx, sums, counts
+
+
+def covertree_update_inducing_parameters(model, data, distance_fn, spatial_resolution):
+    """`optimize.py:19-38`: centroids / cluster means / counts of the finest cover-tree level with
+    empty clusters dropped, returned on the device and in the dtype of `data`."""
+    from .covertree import CoverTree
+    x, y = data
+    tree = CoverTree(distance_fn, data, spatial_resolution=spatial_resolution)
+    means, counts = tree.cluster_mean_and_counts
+    keep = counts.reshape(-1) != 0.0
+    to = (lambda a, like: torch.from_numpy(np.ascontiguousarray(a)).to(device=like.device, dtype=like.dtype)) \
+        if isinstance(x, torch.Tensor) else (lambda a, like: a)
+    return to(tree.centroids[keep], x), to(means[keep], y), to(counts[keep], y)
 
 
 def oips_update_inducing_parameters(model, data, Z, allreduce=None):

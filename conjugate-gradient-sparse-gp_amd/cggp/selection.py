@@ -5,7 +5,7 @@ reference's signatures (`cggp/selection.py:14-153`).  The N x M searches, the pe
 the kernel columns run in libmgp (`nearest_center`, `cluster_stats`, `k_dense`); the sequential
 selection logic stays on the host, as in the reference.  Random draws take a `seed`, or can be
 injected (`initial_centroids`, `perm`, `indices`) -- TensorFlow's streams are not reproducible here.
-The cover tree (`cggp/covertree.py`) is not rebuilt.
+The cover tree lives in `cggp.covertree` (host C++ in libmgp).
 """
 
 import numpy as np

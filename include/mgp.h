@@ -200,6 +200,26 @@ int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t n
 int mgp_profile_enable(mgp_handle* h, int on);
 int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms);
 
+/* ---- next row F3: cover-tree clustering (host code, no GPU, no handle) ----------------------
+ * Replaces the reference's CoverTree class (cggp/covertree.py:26-179), which
+ * covertree_update_inducing_parameters (cggp/optimize.py:19-38) turns into inducing inputs,
+ * cluster means and counts.  x is a HOST pointer [N, D] row-major fp64.  spatial_resolution > 0
+ * derives the level count as the reference does (:54-56), otherwise num_levels is used.  The tree
+ * keeps row indices into x (x is only read during the build).  Levels are read back flat:
+ * level_nodes gives centres [n, D], the parent's position in the level above (-1 for the root) and
+ * the number of rows held; level_rows gives CSR offsets [n+1] and the concatenated row indices
+ * (rows may be NULL to get the offsets only).  Errors: mgp_host_last_error() (thread local). */
+typedef struct mgp_covertree mgp_covertree;
+const char* mgp_host_last_error(void);
+int mgp_covertree_build(const double* x, int64_t N, int D, double spatial_resolution, int num_levels, int lloyds,
+                        int voronoi, mgp_covertree** out);
+void mgp_covertree_destroy(mgp_covertree* t);
+int mgp_covertree_num_levels(const mgp_covertree* t);
+int64_t mgp_covertree_level_size(const mgp_covertree* t, int level);
+double mgp_covertree_level_radius(const mgp_covertree* t, int level);
+int mgp_covertree_level_nodes(const mgp_covertree* t, int level, double* points, int64_t* parent, int64_t* counts);
+int mgp_covertree_level_rows(const mgp_covertree* t, int level, int64_t* offsets, int64_t* rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ def lib():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mgp.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:int|const char\*)\s+(mgp_\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:int|int64_t|double|void|const char\*)\s+(mgp_\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
