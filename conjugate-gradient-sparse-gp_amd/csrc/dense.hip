@@ -166,6 +166,84 @@ __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A,
     }
 }
 
+// ------------------------------------------------------------------ one-RHS product on the upper triangle
+// out = A p for symmetric A reading every off-diagonal 64x64 tile once: the workgroup of tile (I,J),
+// I <= J, forms both A_IJ p_J (a contribution to rows of chunk I) and A_IJ^T p_I (to chunk J), so a
+// CG step streams n^2/2 elements instead of n^2.  Contributions go to Q[other chunk][i] (each slot
+// has exactly one writer) and a second small kernel adds the nt slots of every row in index order:
+// deterministic, no atomics.  (A single-launch form with an arrival ticket per chunk was measured
+// slower: 2080 workgroups each publishing 1 KB write-through cost more than the second launch.)
+template <typename T>
+__global__ __launch_bounds__(256) void symm_gemv_tri_kernel(const T* __restrict__ A, long n,
+                                                            const T* __restrict__ p, T* __restrict__ Q, int nt,
+                                                            const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int TS = 64;
+  __shared__ T rowp[TS][TS + 1];
+  __shared__ T colp[4][TS];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // block -> tile of the row-major enumeration of the upper triangle: row I starts at I nt - I (I-1)/2
+  const long b = blockIdx.x;
+  const double q2 = 2.0 * nt + 1.0;
+  int I = (int)((q2 - sqrt(q2 * q2 - 8.0 * (double)b)) * 0.5);
+  if (I < 0) I = 0;
+  if (I > nt - 1) I = nt - 1;
+  while (I < nt - 1 && (long)(I + 1) * nt - (long)(I + 1) * I / 2 <= b) ++I;
+  while (I > 0 && (long)I * nt - (long)I * (I - 1) / 2 > b) --I;
+  const int J = I + (int)(b - ((long)I * nt - (long)I * (I - 1) / 2));
+  const long r0 = (long)I * TS + 16 * w, c = (long)J * TS + l;
+  T a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = (r0 + r < n && c < n) ? A[(r0 + r) * n + c] : (T)0;
+  const T pj = c < n ? p[c] : (T)0;
+  T cs = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    rowp[16 * w + r][l] = a[r] * pj;
+    const T pi = r0 + r < n ? p[r0 + r] : (T)0;  // wave-uniform address
+    cs = mgp_fma(a[r], pi, cs);
+  }
+  colp[w][l] = cs;
+  __syncthreads();
+  {  // rows of chunk I: thread (row, quarter) adds 16 columns, the quad finishes the row
+    const int row = t >> 2, qd = t & 3;
+    T s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += rowp[row][qd * 16 + k];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const long i = (long)I * TS + row;
+    if (qd == 0 && i < n) Q[(long)J * n + i] = s;
+  }
+  if (I != J && t < TS) {
+    const T s = (colp[0][t] + colp[1][t]) + (colp[2][t] + colp[3][t]);
+    const long i = (long)J * TS + t;
+    if (i < n) Q[(long)I * n + i] = s;
+  }
+}
+
+// out[i] = sum_k Q[k][i], k ascending in four fixed runs per row
+template <typename T>
+__global__ __launch_bounds__(256) void symm_gemv_tri_reduce_kernel(const T* __restrict__ Q, long n, int nt,
+                                                                   T* __restrict__ out,
+                                                                   const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  __shared__ T part[4][64];
+  const int t = threadIdx.x, l = t & 63, pt = t >> 6;
+  const int per = (nt + 3) / 4;
+  const int kb = pt * per, ke = (kb + per < nt) ? kb + per : nt;
+  const long i = (long)blockIdx.x * 64 + l;
+  T s = 0;
+  if (i < n) {
+#pragma unroll 8
+    for (int k = kb; k < ke; ++k) s += Q[(long)k * n + i];
+  }
+  part[pt][l] = s;
+  __syncthreads();
+  if (t < 64 && i < n) out[i] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+}
+
 // ------------------------------------------------------------------ MFMA GEMM
 template <typename T>
 struct Mfma;
@@ -466,6 +544,18 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
   }
   if (Bt > 128) {
     return gemm_nt_launch<T>(h, P, n, Bt, A, n, n, n, out, n, 0, gate);
+  }
+  if (n >= h->tri_min_n && n <= 64L * 32768) {
+    const int nt = (int)((n + 63) / 64);
+    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nt * n * sizeof(T)));
+    const long ntiles = (long)nt * (nt + 1) / 2;
+    hipLaunchKernelGGL((symm_gemv_tri_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, A, n, P,
+                       (T*)h->ws, nt, gate);
+    MGP_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL((symm_gemv_tri_reduce_kernel<T>), dim3((unsigned)nt), dim3(256), 0, h->stream,
+                       (const T*)h->ws, n, nt, out, gate);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
   }
   constexpr int VECW = 16 / sizeof(T);
   const bool vec = (n % VECW) == 0 && (((uintptr_t)A) % 16) == 0;

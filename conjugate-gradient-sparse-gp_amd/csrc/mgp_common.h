@@ -40,6 +40,9 @@ struct mgp_handle {
   // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)
   size_t contract_panel_mb = 2048;
   int contract_nz = 16;
+  // one-RHS symmetric product on the upper triangle (dense.hip); sizes below tri_min_n use the
+  // row-streaming GEMV (MGP_TRI_MIN_N)
+  long tri_min_n = 1024;
   int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
   bool prof_on = false;

@@ -150,7 +150,8 @@ int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t
 
 /* ---- dense symmetric product (row M2: `state.p @ A`, conjugate_gradient.py:65) ---------
  * out[Bt,n] = P[Bt,n] @ A[n,n] for SYMMETRIC A (CG requires it; computed as rows of A dotted
- * with p_b, i.e. P @ A^T). */
+ * with p_b, i.e. P @ A^T).  For Bt = 1 and n >= 1024 only the upper triangle of A (in 64x64
+ * tiles, diagonal tiles whole) is read: each tile serves both A_IJ p_J and A_IJ^T p_I. */
 int mgp_symm_matmul(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P,
                     int64_t Bt, void* out);
 

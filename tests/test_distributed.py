@@ -119,9 +119,14 @@ def _gpu_worker(rank, world, port, out):
     Sv = op.matmul(torch.from_numpy(V).to(dev))
     rhs = torch.from_numpy(np.random.default_rng(1).standard_normal((40, 3))).to(dev)
     sol, (steps, err) = ConjugateGradient(1e-12, max_iterations=3000).solve_with_stats(op, rhs)
+    # sharded build of the subsampled preconditioner (per-rank sample, all-reduced Gram) + PCG
+    from cggp.conjugate_gradient import SubsampledNormalPreconditioner
+    pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=3)
+    psol, (psteps, _) = ConjugateGradient(1e-12, preconditioner=pre, max_iterations=3000).solve_with_stats(op, rhs)
     torch.cuda.synchronize()
     if rank == 0:
-        out.put((Sv.cpu().numpy(), sol.cpu().numpy(), int(steps)))
+        out.put((Sv.cpu().numpy(), sol.cpu().numpy(), int(steps), psol.cpu().numpy(), int(psteps),
+                 pre.sample_rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,7 +140,7 @@ def test_two_rank_sgpr_cg_on_one_gpu():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    Sv, sol, steps = q.get()
+    Sv, sol, steps, psol, psteps, sample_rows = q.get()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
@@ -149,3 +154,5 @@ def test_two_rank_sgpr_cg_on_one_gpu():
     exact = np.linalg.solve(oop.dense(), rhs)
     scale = np.max(np.abs(exact))
     assert np.max(np.abs(sol - exact)) / scale < 1e-6 and np.max(np.abs(o_sol - exact)) / scale < 1e-6
+    assert sample_rows == 2 * (32 * 40 // 2) and psteps < steps
+    assert np.max(np.abs(psol - exact)) / scale < 1e-6

@@ -280,6 +280,33 @@ def test_symm_matmul_fp32(Bt):
     assert relerr(out, P @ A) < 1e-4
 
 
+@pytest.mark.parametrize("n", [1024, 1030, 1091, 2048, 4096])
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-13), (torch.float32, 2e-5)])
+def test_symm_gemv_upper_triangle_path(n, dt, tol):
+    """One RHS, n >= 1024: the product reads only the upper-triangular 64x64 tiles and the last
+    workgroup per chunk sums the contributions.  Repeated launches check that the arrival
+    counters are reset, bit-equal outputs that the summation order is fixed; the strictly lower
+    triangle is poisoned to show it is never read."""
+    from cggp import ops
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    P = rng.standard_normal((1, n))
+    ref = P @ A
+    At = T(A, dt)
+    out1 = ops.symm_matmul(At, T(P, dt))
+    out2 = ops.symm_matmul(At, T(P, dt))
+    assert relerr(out1, ref) < tol
+    assert torch.equal(out1, out2)
+    Ap = A.copy()
+    il = np.tril_indices(n, -64)  # everything below the diagonal tiles
+    Ap[il] = np.nan
+    out3 = ops.symm_matmul(T(Ap, dt), T(P, dt))
+    assert torch.equal(out1, out3)
+    P2 = rng.standard_normal((1, n))
+    assert relerr(ops.symm_matmul(At, T(P2, dt)), P2 @ A) < tol
+
+
 def test_symm_matmul_asymmetric_b_layout_check():
     """A = I with an asymmetric P catches a swapped C/D map in the MFMA epilogue."""
     from cggp import ops

@@ -37,6 +37,36 @@ if "gemv" in which:
         P = torch.randn(Bt, n, dtype=torch.float64, device=dev)
         ms = timeit(lambda: ops.symm_matmul(A, P), reps=20)
         print(f"gemv n={n} Bt={Bt}: {ms*1e3:.1f} us  {8.0*n*n/ms/1e6:.0f} GB/s", flush=True)
+if "stream" in which:  # how fast can one read-only pass go?  (torch reductions as the yardstick)
+    for mb in (134, 537, 2147):
+        x = torch.randn(mb * 1000 * 1000 // 8, dtype=torch.float64, device=dev)
+        ms = timeit(lambda: x.sum(), reps=20)
+        print(f"stream sum {mb} MB: {ms*1e3:.1f} us  {x.numel()*8/ms/1e6:.0f} GB/s", flush=True)
+    for n in (4096, 8192, 16384):
+        A = torch.randn(n, n, dtype=torch.float64, device=dev)
+        P = torch.randn(1, n, dtype=torch.float64, device=dev)
+        ms = timeit(lambda: ops.symm_matmul(A, P), reps=20)
+        print(f"gemv n={n}: {ms*1e3:.1f} us  {8.0*n*n/ms/1e6:.0f} GB/s", flush=True)
+        ms = timeit(lambda: A @ P[0], reps=20)
+        print(f"   torch mv: {ms*1e3:.1f} us  {8.0*n*n/ms/1e6:.0f} GB/s", flush=True)
+if "cg64" in which:  # per-iteration cost of the 64-probe CG at C3's M
+    from cggp.conjugate_gradient import conjugate_gradient
+    n = 4096
+    Z = torch.randn(n, 8, dtype=torch.float64, device=dev)
+    A = kernels.SquaredExponential(1.0, [1.0] * 8).K(Z) + 0.1 * torch.eye(n, dtype=torch.float64, device=dev)
+    for Bt in (1, 8, 64, 128, 1024):
+        B = torch.randn(Bt, n, dtype=torch.float64, device=dev)
+        k = 200
+        ms = timeit(lambda: conjugate_gradient(A, B, None, 0.0, max_iterations=k, max_steps_cycle=k + 1, check_every=k), reps=3, warm=1)
+        print(f"cg n={n} Bt={Bt}: {ms/k*1e3:.1f} us/iteration", flush=True)
+if "kuu" in which:
+    Z = torch.randn(4096, 8, dtype=torch.float64, device=dev)
+    kk = kernels.SquaredExponential(1.0, [1.0] * 8)
+    lam = torch.rand(4096, dtype=torch.float64, device=dev)
+    ms = timeit(lambda: kernels.Kuu(Z, kk, jitter=0.0, diag_add=lam))
+    print(f"Kuu M=4096 with diag_add: {ms*1e3:.1f} us", flush=True)
+    ms = timeit(lambda: kk.K(Z))
+    print(f"K(Z) M=4096: {ms*1e3:.1f} us", flush=True)
 if "kdense" in which:
     for M, D in [(4096, 8), (8192, 2)]:
         Z = torch.randn(M, D, dtype=torch.float64, device=dev)
