@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict
 // Fused common-case step (no refresh, Eye or Jacobi): the whole update of one RHS with its
 // elements held in registers (EPT per thread), two block reductions instead of four, and the
 // iteration bookkeeping (`any` over the RHS flags, step counter, next gate) done by the last
-// workgroup to arrive -- agent-scope fence + ticket, no extra launch.
+// workgroup to arrive -- write-through flag + ticket, no extra launch.
 template <typename T, int EPT, int NT>
 __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict__ ctrl, T* __restrict__ v,
                                                              T* __restrict__ r, T* __restrict__ p,
@@ -238,18 +238,21 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
     rz[blockIdx.x] = s_rz;
     err[blockIdx.x] = (T)0.5 * s_rz;
     __hip_atomic_store(&over[blockIdx.x], ((T)0.5 * s_rr > thr) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();  // release: this workgroup's flag is visible before its ticket
-    // hipcc may drop the wait behind the L2 write-back when it can prove the vmcnt scoreboard empty
-    // (MI355X_MICROARCH.md, compiler hazard); inline asm is invisible to that pass
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned tk = atomicAdd(&ctrl->ticket, 1u);
-    last_flag = (tk == gridDim.x - 1) ? 1 : 0;
+    if (gridDim.x == 1) {
+      last_flag = 1;  // one right-hand side: nothing to hand over
+    } else {
+      // hand-off without fences (cdna_hip_programming.md G16, sc1 form): the flag above is a
+      // write-through store of this lane, drained here, then the ticket; the last arriver reads the
+      // flags with sc1 loads behind the barrier.  (__threadfence() on both sides cost ~3.5 us each.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned tk = atomicAdd(&ctrl->ticket, 1u);
+      last_flag = (tk == gridDim.x - 1) ? 1 : 0;
+    }
   }
   __syncthreads();
   if (last_flag) {  // last workgroup to arrive: every flag has been published
     __shared__ int any;
     if (t == 0) any = 0;
-    __threadfence();  // acquire
     __syncthreads();
     int a = 0;
     for (long b = t; b < (long)gridDim.x; b += NT)
