@@ -520,10 +520,185 @@ __global__ __launch_bounds__(512) void symm_skinny_kernel(const T* __restrict__ 
   }
 }
 
+// 2 <= Bt <= 128, second form: the P panel is staged through LDS and shared by the four row tiles of a
+// workgroup.  The register-operand form above fetches one P value per lane and MFMA from L2 (at
+// Bt = 64: 537 MB of L2->L1 traffic against 134 MB of A, the measured limiter); here a workgroup
+// covers 64 rows of A x one slice of the contraction index, 8 waves = 4 row tiles x 2 halves of a
+// KW-wide k step, P for the step is written to LDS once, already in MFMA operand order
+// ([half][b tile][element][lane group][row]: a wave's operand read is 512 contiguous bytes, a
+// staging store 128 contiguous bytes per 16 lanes -- both conflict-free), A and the next P step are
+// register-prefetched one step ahead.  Slices of the contraction index (grid.y) write their own
+// [Bt,n] partial, summed in slice order by skinny_reduce_kernel -- deterministic.  P is read in its
+// original [Bt,n] layout (no transpose pass).
+template <typename T, int NBT, int KW, bool VEC>
+__global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restrict__ A, long n,
+                                                              const T* __restrict__ P, long Bt,
+                                                              T* __restrict__ dst, long kr_len,
+                                                              const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int EH = KW / 2;                     // k per half step
+  constexpr int EPL = EH / 4;                    // consecutive k per lane and half step (4 or 8)
+  constexpr int PPB = KW / 4;                    // 4-element pieces per row of P and step
+  constexpr int STEP = NBT * 16 * KW;            // elements of P per step
+  constexpr int NPIECE = NBT * 16 * PPB;         // pieces per step
+  constexpr int NV = (NPIECE + 511) / 512;       // pieces staged per thread and step
+  constexpr int REDN = NBT * 1024;               // epilogue exchange: 4 tiles x NBT x 4 x 64
+  constexpr int LDSN = 2 * STEP > REDN ? 2 * STEP : REDN;
+  using Acc = typename Mfma<T>::Acc;
+  __shared__ __attribute__((aligned(32))) T Pl[LDSN];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wj = wave & 3, wk = wave >> 2;
+  const int jj = lane & 15, g = lane >> 4;
+  const long j0 = (long)blockIdx.x * 64 + wj * 16;
+  const long j = j0 + jj < n ? j0 + jj : n - 1;
+  const T* arow = A + j * n;
+  const long k_begin = (long)blockIdx.y * kr_len;
+  const long k_end = k_begin + kr_len < n ? k_begin + kr_len : n;
+  dst += (long)blockIdx.y * Bt * n;
+  Acc acc[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
+
+  T a[EPL], an[EPL], ps[NV][4];
+  auto load4 = [&](const T* base, long k, bool ok, T* v) {
+    if (VEC) {
+      if (ok && k + 3 < n) {
+        using V4 = __attribute__((ext_vector_type(4))) T;
+        const V4 x = *reinterpret_cast<const V4*>(base + k);
+        v[0] = x[0];
+        v[1] = x[1];
+        v[2] = x[2];
+        v[3] = x[3];
+      } else {
+        v[0] = v[1] = v[2] = v[3] = (T)0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (ok && k + e < n) ? base[k + e] : (T)0;
+    }
+  };
+  auto load_step = [&](long kr, T* av) {
+#pragma unroll
+    for (int q = 0; q < EPL / 4; ++q) load4(arow, kr + wk * EH + EPL * g + 4 * q, true, av + 4 * q);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = t + 512 * i;
+      const int kq = (v >> 4) % PPB, b = ((v >> 4) / PPB) * 16 + (v & 15);
+      load4(P + (long)b * n, kr + 4 * kq, b < Bt && v < NPIECE, ps[i]);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = t + 512 * i;
+      if (v < NPIECE) {
+        const int kq = (v >> 4) % PPB, bt = (v >> 4) / PPB;
+        const int kh = kq / (EH / 4), kk0 = 4 * (kq % (EH / 4));
+        const int gg = kk0 / EPL, e0 = kk0 % EPL;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          Pl[buf * STEP + ((((kh * NBT + bt) * EPL + e0 + e) * 4 + gg) * 16 + (v & 15))] = ps[i][e];
+      }
+    }
+  };
+  if (k_begin < k_end) {
+    load_step(k_begin, a);
+    stage(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long kr = k_begin; kr < k_end; kr += KW, buf ^= 1) {
+    const bool more = kr + KW < k_end;
+    if (more) load_step(kr + KW, an);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      T pf[NBT];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) pf[bt] = Pl[buf * STEP + ((((wk * NBT + bt) * EPL + e) * 4 + g) * 16 + jj)];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[bt], a[e], acc[bt]);
+    }
+    if (more) {
+      stage(buf ^ 1);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) a[e] = an[e];
+    }
+    __syncthreads();
+  }
+  // the two k halves of a row tile meet in LDS (upper half stores, lower half adds and writes)
+  T* red = Pl;
+  if (wk == 1) {
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wj * NBT + bt) * 4 + r) * 64 + lane] = acc[bt][r];
+  }
+  __syncthreads();
+  if (wk == 0) {
+    const long jo = j0 + jj;
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long b = bt * 16 + Mfma<T>::row(lane, r);
+        if (b < Bt && jo < n) dst[b * n + jo] = acc[bt][r] + red[((wj * NBT + bt) * 4 + r) * 64 + lane];
+      }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const T* __restrict__ part, long tot, int ks,
+                                                            T* __restrict__ out, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= tot) return;
+  T s = part[e];
+  for (int z = 1; z < ks; ++z) s += part[(long)z * tot + e];
+  out[e] = s;
+}
+
+template <typename T, int NBT>
+int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out, const int* gate) {
+  constexpr int KW = (NBT * 16 * 64 * 2 * sizeof(T) <= 65536) ? 64 : 32;  // two staging buffers within 64 KB
+  const long jg = (n + 63) / 64;
+  long ks = h->num_cus / jg;
+  if (ks > 8) ks = 8;
+  if (ks < 1) ks = 1;
+  long kr_len = ((n + ks - 1) / ks + KW - 1) / KW * KW;
+  ks = (n + kr_len - 1) / kr_len;
+  T* dst = out;
+  if (ks > 1) {
+    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)ks * Bt * n * sizeof(T)));
+    dst = (T*)h->ws;
+  }
+  const bool vec = (n % 4) == 0 && (((uintptr_t)A) % 32) == 0 && (((uintptr_t)P) % 32) == 0;
+  dim3 grid((unsigned)jg, (unsigned)ks);
+  if (vec)
+    hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, true>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
+                       kr_len, gate);
+  else
+    hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, false>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
+                       kr_len, gate);
+  MGP_LAUNCH_CHECK(h);
+  if (ks > 1) {
+    const long tot = Bt * n;
+    hipLaunchKernelGGL((skinny_reduce_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (const T*)dst, tot, (int)ks, out, gate);
+    MGP_LAUNCH_CHECK(h);
+  }
+  return MGP_OK;
+}
+
 template <typename T>
 int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out, const int* gate) {
   if (Bt >= 2 && Bt <= 128) {
     const int nbt = Bt <= 16 ? 1 : (Bt <= 32 ? 2 : (Bt <= 64 ? 4 : 8));
+    if (h->skinny_mode == 1) {  // P staged through LDS (default); MGP_SKINNY=reg selects the form below
+      if (nbt == 1) return symm_skinny_lds_launch<T, 1>(h, A, n, P, Bt, out, gate);
+      if (nbt == 2) return symm_skinny_lds_launch<T, 2>(h, A, n, P, Bt, out, gate);
+      if (nbt == 4) return symm_skinny_lds_launch<T, 4>(h, A, n, P, Bt, out, gate);
+      return symm_skinny_lds_launch<T, 8>(h, A, n, P, Bt, out, gate);
+    }
     const int BP = 16 * nbt;
     MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)n * BP * sizeof(T)));
     T* Pt = (T*)h->ws;
