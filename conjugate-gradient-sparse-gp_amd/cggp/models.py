@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .conjugate_gradient import ConjugateGradient, SgprNormalOperator
+from .conjugate_gradient import ConjugateGradient, SgprNormalOperator, SubsampledNormalPreconditioner
 from .kernels import InducingPoints, Kuf, Kuu, inducingpoint_wrapper
 from .likelihoods import Gaussian
 
@@ -328,7 +328,18 @@ class SGPR:
     """
 
     def __init__(self, data, kernel, inducing_variable, noise_variance, conjugate_gradient=None, *,
-                 jitter=1e-6, allreduce=None, num_data=None):
+                 jitter=1e-6, allreduce=None, num_data=None, preconditioner="auto", explicit_rhs=8,
+                 kmm_solver="cholesky"):
+        """`preconditioner`: "auto" (the subsampled normal-equation preconditioner when this
+        rank holds at least 32 rows per inducing point, else none), None, or a
+        `CGPreconditioner` for the [M,M] system.  `explicit_rhs`: solves on S with at least this
+        many right-hand sides form S once on the matrix cores (`ops.kmn_knm`, 2NM^2 flops) and run
+        the dense CG on it -- a matrix-free step costs two N x M sweeps per right-hand-side chunk,
+        so beyond a handful of columns the explicit matrix is cheaper (0 disables).
+        `kmm_solver`: how `K_*m (Kmm+jI)^-1 K_m*` of the predictive variance is formed --
+        "cholesky" (GPflow's own `L = chol(Kmm + jitter I)`, one [M,M] factorisation, cached) or
+        "cg" (the model's `conjugate_gradient`; Kmm + 1e-6 I is badly conditioned, so this takes
+        hundreds of steps)."""
         self.X, self.Y = data
         self.kernel = kernel
         self.inducing_variable = inducingpoint_wrapper(inducing_variable)
@@ -337,8 +348,17 @@ class SGPR:
         self.jitter = float(jitter)
         self.allreduce = allreduce
         self.num_data = num_data if num_data is not None else self.X.shape[0]
+        self.preconditioner = preconditioner
+        self.explicit_rhs = int(explicit_rhs)
+        if kmm_solver not in ("cholesky", "cg"):
+            raise ValueError(f"unknown kmm_solver {kmm_solver!r}")
+        self.kmm_solver = kmm_solver
+        self._Lmm = None
         self._alpha = None
         self._op = None
+        self._cg_S = None
+        self._S = None
+        self._KK = None
 
     def operator(self):
         if self._op is None:
@@ -346,6 +366,44 @@ class SGPR:
                                           self.likelihood.variance, jitter=self.jitter,
                                           allreduce=self.allreduce)
         return self._op
+
+    def solver(self):
+        """The CG used on S: the model's `conjugate_gradient` settings plus the preconditioner."""
+        if self._cg_S is None:
+            cg, pre = self.conjugate_gradient, self.preconditioner
+            if isinstance(pre, str):
+                if pre != "auto":
+                    raise ValueError(f"unknown preconditioner {pre!r}")
+                M = self.inducing_variable.Z.shape[0]
+                pre = SubsampledNormalPreconditioner(self.operator()) if self.X.shape[0] >= 32 * M else None
+            if pre is None:
+                self._cg_S = cg
+            else:
+                self._cg_S = ConjugateGradient(cg.error_threshold, pre, cg.max_iterations, cg.max_steps_cycle,
+                                               min_float=cg.min_float, check_every=cg.check_every)
+        return self._cg_S
+
+    def dense_S(self):
+        """S = s2 (Kmm + jitter I) + K_mn K_nm as an [M,M] matrix (formed once, cached)."""
+        if self._S is None:
+            self._S = torch.add(self.kmn_knm(), self.operator().Kmm, alpha=self.likelihood.variance)
+        return self._S
+
+    def kmn_knm(self):
+        """K_mn K_nm [M,M] on the matrix cores, summed over ranks (formed once, cached)."""
+        if self._KK is None:
+            Z = self.inducing_variable.Z
+            KK = ops.kmn_knm(self.kernel.spec(Z.shape[1]), self.X, Z)
+            if self.allreduce is not None:
+                self.allreduce(KK.view(-1))
+            self._KK = KK
+        return self._KK
+
+    def solve_S(self, rhs):
+        """S^-1 rhs for rhs [M, R]: matrix-free for a few columns, explicit S beyond `explicit_rhs`."""
+        if self._S is not None or (self.explicit_rhs > 0 and rhs.shape[1] >= self.explicit_rhs):
+            return self.solver()(self.dense_S(), rhs)
+        return self.solver()(self.operator(), rhs)
 
     def _Kmn_y(self):
         Z = self.inducing_variable.Z
@@ -356,7 +414,7 @@ class SGPR:
 
     def alpha(self):
         if self._alpha is None:
-            self._alpha = self.conjugate_gradient(self.operator(), self._Kmn_y())
+            self._alpha = self.solve_S(self._Kmn_y())
         return self._alpha
 
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
@@ -364,9 +422,13 @@ class SGPR:
         iv, kernel = self.inducing_variable, self.kernel
         mean = ops.knm_matvec(kernel.spec(Xnew.shape[1]), Xnew, iv.Z, self.alpha())
         Kms = Kuf(iv, kernel, Xnew)
-        Kmm_j = Kuu(iv, kernel, jitter=self.jitter)
-        W1 = self.conjugate_gradient(Kmm_j, Kms)
-        W2 = self.conjugate_gradient(self.operator(), Kms)
+        if self.kmm_solver == "cholesky":
+            if self._Lmm is None:
+                self._Lmm = torch.linalg.cholesky(self.operator().Kmm)  # Kmm + jitter I
+            W1 = torch.cholesky_solve(Kms, self._Lmm)
+        else:
+            W1 = self.conjugate_gradient(self.operator().Kmm, Kms)
+        W2 = self.solve_S(Kms)
         var = kernel.K_diag(Xnew) - ops.colwise_dot(Kms, W1) + self.likelihood.variance * ops.colwise_dot(Kms, W2)
         return mean, var[:, None]
 
@@ -376,11 +438,9 @@ class SGPR:
         Z = iv.Z
         s2 = self.likelihood.variance
         N = self.num_data
-        spec = kernel.spec(Z.shape[1])
-        KK = ops.kmn_knm(spec, self.X, Z)  # K_mn K_nm on the matrix cores
+        KK = self.kmn_knm()  # on the matrix cores; shared with the explicit-S solves
         yy = ops.dot_all(self.Y, self.Y)
         if self.allreduce is not None:
-            self.allreduce(KK.view(-1))
             t = torch.tensor([yy], dtype=torch.float64, device=Z.device)
             self.allreduce(t)
             yy = t.item()

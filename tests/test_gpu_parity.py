@@ -710,6 +710,27 @@ def test_sgpr_cg_model():
     assert abs(e - e0) / abs(e0) < 1e-8
 
 
+@pytest.mark.parametrize("pre,explicit,kmm", [(None, 0, "cg"), ("auto", 0, "cholesky"), (None, 8, "cholesky"),
+                                              ("auto", 8, "cg")])
+def test_sgpr_solve_paths(pre, explicit, kmm):
+    """Matrix-free / explicit-S solves, with and without the subsampled preconditioner: the same
+    predictions as the two-Cholesky closed form."""
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import SGPR
+    X, y, Z, k, ko, u, counts = model_problem("matern32", N=4000, M=40)
+    m = SGPR((T(X), T(y)), k, T(Z), 0.1, ConjugateGradient(1e-13, max_iterations=5000), jitter=1e-6,
+             preconditioner=pre, explicit_rhs=explicit, kmm_solver=kmm)
+    ref = om.SGPR((X, y), ko, Z, 0.1, jitter=1e-6)
+    Xs = X[:50] + 0.05
+    mu, var = m.predict_f(T(Xs))
+    mu0, var0 = ref.predict_f(Xs)
+    assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < 1e-5
+    assert (m._S is not None) == (explicit > 0)
+    steps = int(m.solver().last_stats[0])
+    if pre == "auto":
+        assert steps < 40, steps  # the identity-preconditioned solve takes hundreds here
+
+
 # ------------------------------------------------------------------ F1: assignment + stats
 @pytest.mark.parametrize("dist", ["sqeuclidean", "euclidean", "covariance", "correlation"])
 def test_nearest_center(dist):
