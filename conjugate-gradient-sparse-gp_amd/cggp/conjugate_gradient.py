@@ -361,19 +361,34 @@ class SubsampledNormalPreconditioner(DensePreconditioner):
         gen = torch.Generator().manual_seed(int(seed))
         sel = torch.randperm(N_local, generator=gen)[:n_s].to(X.device)
         G = ops.kmn_knm(operator.spec, X[sel].contiguous(), Z)  # Ks^T Ks  [M, M]
-        tot = torch.tensor([float(n_s), float(N_local)], dtype=G.dtype, device=X.device)
+        tot = torch.tensor([float(n_s), float(N_local)], dtype=torch.float64, device=X.device)
         if operator.allreduce is not None:
             operator.allreduce(G.view(-1))
             operator.allreduce(tot)
         n_tot, N_tot = float(tot[0]), float(tot[1])
-        P = operator.s2 * operator.Kmm + (N_tot / n_tot) * G
-        if jitter:
-            P = P + jitter * torch.eye(M, dtype=P.dtype, device=P.device)
+        # factorise in fp64 whatever the operator's dtype: P inherits cond(S) ~ cond(Kmm)^2
+        P = operator.s2 * operator.Kmm.double() + (N_tot / n_tot) * G.double()
         P = 0.5 * (P + P.t())
-        L = torch.linalg.cholesky(P)
+        eye = torch.eye(M, dtype=P.dtype, device=P.device)
+        # In a dtype narrower than fp64 the operator itself is only known to eps ||S||: eigenvalues of
+        # P below that are noise, and P^-1 rounded to that dtype would not stay positive definite
+        # (measured: the fp32 solve diverges).  Lift them to the rounding level -- nothing is lost.
+        eps = float(torch.finfo(operator.dtype).eps)
+        bump = float(jitter) if operator.dtype == torch.float64 else max(float(jitter), eps * float(P.diagonal().sum()))
+        floor = eps * float(P.diagonal().mean())
+        for _ in range(12):
+            L, info = torch.linalg.cholesky_ex(P + bump * eye if bump else P)
+            if int(info) == 0:
+                break
+            # not numerically positive definite (rounding of the Gram term in the operator's dtype):
+            # lift the spectrum by a step relative to that rounding and retry
+            bump = max(10.0 * bump, floor)
+        else:
+            raise RuntimeError("SubsampledNormalPreconditioner: P is not positive definite")
+        self.jitter_used = bump
         Pinv = torch.cholesky_inverse(L)
         self.sample_rows = int(n_tot)
-        super().__init__((0.5 * (Pinv + Pinv.t())).contiguous())
+        super().__init__((0.5 * (Pinv + Pinv.t())).to(operator.dtype).contiguous())
 
 
 # --------------------------------------------------------------------------- solver

@@ -537,6 +537,32 @@ def test_sgpr_subsampled_preconditioner():
     assert np.max(np.abs(S @ (sol.cpu().numpy() - o_sol))) < 1e-4 * np.max(np.abs(b)) * 1e-2
 
 
+def test_sgpr_subsampled_preconditioner_fp32():
+    """fp32 operator: P is factorised in fp64 and applied in fp32; the solve reaches the fp32 floor
+    of the system in a few steps where the identity-preconditioned one stalls far above it."""
+    from cggp.conjugate_gradient import ConjugateGradient, SgprNormalOperator, SubsampledNormalPreconditioner
+    from cggp import kernels as ck
+    rng = np.random.default_rng(12)
+    N, M, D = 20000, 256, 2
+    X = rng.uniform(-3, 3, (N, D))
+    Z = X[rng.choice(N, M, replace=False)].copy()
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    kern = ck.SquaredExponential(variance=1.0, lengthscales=[1.0, 1.0])
+    okern = ok.Kernel("se", 1.0, np.ones(2))
+    op = SgprNormalOperator(kern, T(X, torch.float32), T(Z, torch.float32), 0.1, jitter=1e-4)
+    Kmn = okern.K(Z, X)
+    S = 0.1 * (okern.K(Z, Z) + 1e-4 * np.eye(M)) + Kmn @ Kmn.T
+    b = Kmn @ y
+    P = SubsampledNormalPreconditioner(op, rows_per_inducing=32)
+    assert P.inverse.dtype == torch.float32
+    bt = T(b, torch.float32)
+    sol, (steps, _) = ConjugateGradient(0.0, preconditioner=P, max_iterations=30).solve_with_stats(op, bt)
+    sol_eye, _ = ConjugateGradient(0.0, max_iterations=30).solve_with_stats(op, bt)
+    res = np.linalg.norm(S @ sol.double().cpu().numpy() - b) / np.linalg.norm(b)
+    res_eye = np.linalg.norm(S @ sol_eye.double().cpu().numpy() - b) / np.linalg.norm(b)
+    assert res < 5e-4 and res < 0.1 * res_eye, (res, res_eye)
+
+
 def test_cg_fp32():
     from cggp.conjugate_gradient import ConjugateGradient
     A, rhs = cg_problem(n=80, noise=0.5)
