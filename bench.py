@@ -38,6 +38,7 @@ SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3
 EXEC_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
 EXEC_VALU_INSTR_PER_PAIR = lambda D, R: D + 8 + 3 + R
 NUM_SIMDS, MAX_CLOCK_HZ, FP64_CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
 
 
 def main():
@@ -149,6 +150,8 @@ def main():
         NUM_SIMDS * MAX_CLOCK_HZ)
     bytes_launch = float(esize) * (n_local * D + M * D + M * R + n_local * R)
     ach_tflops = flops_launch / (sweep_ms * 1e-3) / 1e12
+    vector_peak = FP64_VECTOR_PEAK_TFLOPS if esize == 8 else FP32_VECTOR_PEAK_TFLOPS
+    flop_model_exact = esize == 8 and kname == "se"
     ach_gbps = bytes_launch / (sweep_ms * 1e-3) / 1e9
     equiv_gemv_gbps = float(esize) * n_local * M / (sweep_ms * 1e-3) / 1e9
 
@@ -280,15 +283,18 @@ def main():
                 "bound_note": "fp64 compute roofline: on MI355X the fp64 vector and matrix peaks are the same 78.6 "
                               "TFLOP/s and share the ALUs; this kernel issues VALU (DESIGN.md 4.1), it is not HBM-bound "
                               "(SURVEY 8d) -- the hbm figures BASELINE.json asks for are in the nested object",
-                "kernel": "sweep_kernel<double,8,SE,1> (K_nm.p and K_mn.u are the same symbol)",
-                "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                "kernel": f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1> (K_nm.p and K_mn.u are the "
+                          "same symbol)",
+                "achieved": ach_tflops, "peak": vector_peak, "unit": "TFLOP/s",
+                "frac": ach_tflops / vector_peak,
+                "flop_model": "counted from the fp64 SE fast path of csrc/sweep.hip" if flop_model_exact else
+                              "the fp64 SE instruction count applied to another dtype/kernel: approximate",
                 "flop_per_pair": EXEC_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
                 "valu_instr_per_pair": EXEC_VALU_INSTR_PER_PAIR(D, R),
                 "valu_issue_frac_at_2.4GHz": issue_s / (sweep_ms * 1e-3),
                 "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
                 "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
-                                             / FP64_VECTOR_PEAK_TFLOPS,
+                                             / vector_peak,
                 "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value),
                 "traffic": traffic,
                 "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
