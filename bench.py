@@ -139,10 +139,14 @@ def main():
     hd.check(hd.lib.mgp_profile_enable(hd.h, 1))
     run_steps(args.steps)
     import ctypes
-    launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0.0)
-    hd.check(hd.lib.mgp_profile_read(hd.h, ctypes.byref(launches), ctypes.byref(total_ms)))
+    launches = ctypes.c_int64(0)
+    each = (ctypes.c_double * (2 * args.steps + 8))()
+    hd.check(hd.lib.mgp_profile_read_each(hd.h, each, len(each), ctypes.byref(launches)))
     hd.check(hd.lib.mgp_profile_enable(hd.h, 0))
-    sweep_ms = total_ms.value / max(1, launches.value)
+    durs = np.array(each[:min(launches.value, len(each))], dtype=np.float64)
+    sweep_ms = float(durs.mean()) if durs.size else float("nan")
+    sweep_pct = {"median_ms": float(np.median(durs)), "p10_ms": float(np.percentile(durs, 10)),
+                 "p90_ms": float(np.percentile(durs, 90))} if durs.size else None
     R = 1
     pairs_launch = float(n_local) * M
     flops_launch = pairs_launch * EXEC_FLOPS_PER_PAIR(D, R)
@@ -295,7 +299,8 @@ def main():
                 "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
                 "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
                                              / vector_peak,
-                "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value),
+                "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value), "launch_percentiles": sweep_pct,
+                "gpair_evals_per_s": pairs_launch / (sweep_ms * 1e-3) / 1e9,
                 "traffic": traffic,
                 "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_launch,

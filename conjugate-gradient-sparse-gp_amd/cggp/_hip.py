@@ -106,6 +106,7 @@ SIGNATURES = {
     "mgp_k_dense_vjp": (_I, [_P, _KP, _P, _L, _P, _L, _P, _L, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),
+    "mgp_profile_read_each": (_I, [_P, ctypes.POINTER(_D), _L, ctypes.POINTER(_L)]),
     # host-only entry points (cover tree, row F3)
     "mgp_host_last_error": (ctypes.c_char_p, []),
     "mgp_covertree_build": (_I, [_P, _L, _I, _D, _I, _I, _I, ctypes.POINTER(_P)]),

@@ -101,6 +101,20 @@ extern "C" int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_
   return MGP_OK;
 }
 
+extern "C" int mgp_profile_read_each(mgp_handle* h, double* ms_out, int64_t capacity, int64_t* launches) {
+  if (!h || !launches || (capacity > 0 && !ms_out)) return MGP_E_BADARG;
+  MGP_HIP(h, hipStreamSynchronize(h->stream));
+  const int64_t n = (int64_t)h->prof_used;
+  for (int64_t i = 0; i < n && i < capacity; ++i) {
+    float ms = 0.f;
+    MGP_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[i].first, h->prof_ev[i].second));
+    ms_out[i] = ms;
+  }
+  *launches = n;
+  h->prof_used = 0;
+  return MGP_OK;
+}
+
 namespace {
 
 template <typename T>

@@ -200,6 +200,9 @@ int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t n
  * sum of their durations in milliseconds, and resets the counters. */
 int mgp_profile_enable(mgp_handle* h, int on);
 int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms);
+/* as mgp_profile_read, but one duration per bracketed launch (the first `capacity` of them) so the
+ * caller can report median / percentiles; *launches receives the number recorded. */
+int mgp_profile_read_each(mgp_handle* h, double* ms_out, int64_t capacity, int64_t* launches);
 
 /* ---- next row F3: cover-tree clustering (host code, no GPU, no handle) ----------------------
  * Replaces the reference's CoverTree class (cggp/covertree.py:26-179), which
