@@ -14,7 +14,9 @@ namespace {
 
 constexpr int NT = 256;
 
-template <typename T, int DP, int KIND>
+// RPT rows per thread: one LDS read of a centre feeds RPT distance chains (with one row per thread the
+// kernel was LDS-issue bound: 5 operand reads per 13 VALU instructions)
+template <typename T, int DP, int KIND, int RPT>
 __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, long N, const T* __restrict__ Z,
                                                      long M, int D, SweepParams prm, int dist_type,
                                                      long* __restrict__ idx, T* __restrict__ best) {
@@ -22,19 +24,28 @@ __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, lo
   constexpr int PS = (DP + 1 + 1) & ~1;
   __shared__ __attribute__((aligned(16))) T tile[TB * PS];
   const int t = threadIdx.x;
-  long i = (long)blockIdx.x * NT + t;
-  const bool live = i < N;
-  if (!live) i = N - 1;
-  T a[DP];
-  T a2 = 0;
+  const long i0 = (long)blockIdx.x * (NT * RPT) + t;
+  T a[RPT][DP];
+  T a2[RPT];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) {
-    T v = d < D ? X[i * D + d] * (T)prm.inv_ls[d] : (T)0;
-    a[d] = v;
-    a2 = mgp_fma(v, v, a2);
+  for (int q = 0; q < RPT; ++q) {
+    long i = i0 + (long)q * NT;
+    if (i >= N) i = N - 1;
+    a2[q] = 0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      T v = d < D ? X[i * D + d] * (T)prm.inv_ls[d] : (T)0;
+      a[q][d] = v;
+      a2[q] = mgp_fma(v, v, a2[q]);
+    }
   }
-  T bs = (T)INFINITY;
-  long bj = 0;
+  T bs[RPT];
+  int bj[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    bs[q] = (T)INFINITY;
+    bj[q] = 0;
+  }
   for (long j0 = 0; j0 < M; j0 += TB) {
     __syncthreads();
     if (t < TB) {
@@ -53,28 +64,38 @@ __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, lo
     const int lim = (M - j0) < TB ? (int)(M - j0) : TB;
     for (int jj = 0; jj < lim; ++jj) {
       const T* p = &tile[jj * PS];
-      T s = p[DP] + a2;  // |a|^2 + |b|^2 - 2 a.b  (GPflow's expansion)
+      T pv[DP + 1];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) s = mgp_fma(-a[d], p[d], s);
-      if (s < bs) {
-        bs = s;
-        bj = j0 + jj;
+      for (int d = 0; d <= DP; ++d) pv[d] = p[d];
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        T s = pv[DP] + a2[q];  // |a|^2 + |b|^2 - 2 a.b  (GPflow's expansion)
+#pragma unroll
+        for (int d = 0; d < DP; ++d) s = mgp_fma(-a[q][d], pv[d], s);
+        if (s < bs[q]) {  // strict: first index on ties while j ascends
+          bs[q] = s;
+          bj[q] = (int)j0 + jj;
+        }
       }
     }
   }
-  if (!live) return;
-  idx[i] = bj;
-  if (best != nullptr) {
-    T o;
-    if (dist_type == 0) {
-      o = bs;
-    } else if (dist_type == 1) {
-      o = mgp_sqrt(bs > 0 ? bs : (T)0);
-    } else {
-      const T rho = mgp_profile<KIND, T>(-bs, (T)prm.clamp);  // k / variance
-      o = dist_type == 2 ? (T)2 * (T)prm.variance * ((T)1 - rho) : (T)1 - rho;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const long i = i0 + (long)q * NT;
+    if (i >= N) continue;
+    idx[i] = bj[q];
+    if (best != nullptr) {
+      T o;
+      if (dist_type == 0) {
+        o = bs[q];
+      } else if (dist_type == 1) {
+        o = mgp_sqrt(bs[q] > 0 ? bs[q] : (T)0);
+      } else {
+        const T rho = mgp_profile<KIND, T>(-bs[q], (T)prm.clamp);  // k / variance
+        o = dist_type == 2 ? (T)2 * (T)prm.variance * ((T)1 - rho) : (T)1 - rho;
+      }
+      best[i] = o;
     }
-    best[i] = o;
   }
 }
 
@@ -131,15 +152,28 @@ __global__ __launch_bounds__(NT) void cluster_reduce_kernel(const T* __restrict_
 template <typename T, int KIND>
 int nearest_dp(mgp_handle* h, const SweepParams& prm, int D, int dist_type, const T* X, long N, const T* Z, long M,
                long* idx, T* best) {
-  dim3 grid((unsigned)((N + NT - 1) / NT));
-#define MGP_NC(DPV)                                                                                             \
-  hipLaunchKernelGGL((nearest_kernel<T, DPV, KIND>), grid, dim3(NT), 0, h->stream, X, N, Z, M, D, prm, dist_type, \
+  // rows per thread: as many as still leave two workgroups per CU (C2's 10^5 rows stay at one)
+  int rpt = D <= 8 ? 4 : 2;
+  while (rpt > 1 && (N + (long)NT * rpt - 1) / ((long)NT * rpt) < 2L * h->num_cus) rpt >>= 1;
+  dim3 grid((unsigned)((N + (long)NT * rpt - 1) / ((long)NT * rpt)));
+#define MGP_NC1(DPV, RV)                                                                                         \
+  hipLaunchKernelGGL((nearest_kernel<T, DPV, KIND, RV>), grid, dim3(NT), 0, h->stream, X, N, Z, M, D, prm, dist_type, \
                      idx, best)
+#define MGP_NC(DPV)          \
+  do {                       \
+    if (rpt == 4) {          \
+      if (DPV <= 8) MGP_NC1(DPV, 4); \
+    } else if (rpt == 2)     \
+      MGP_NC1(DPV, 2);       \
+    else                     \
+      MGP_NC1(DPV, 1);       \
+  } while (0)
   if (D <= 2) MGP_NC(2);
   else if (D <= 4) MGP_NC(4);
   else if (D <= 8) MGP_NC(8);
   else if (D <= 16) MGP_NC(16);
   else MGP_NC(32);
+#undef MGP_NC1
 #undef MGP_NC
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;
@@ -189,7 +223,7 @@ extern "C" int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_t
   MGP_TRY(mgp_check_kernel(h, k));
   MGP_TRY(mgp_check_fused_dim(h, k, "nearest_center"));
   if (dist_type < 0 || dist_type > 3) return mgp_fail(h, MGP_E_BADARG, "bad dist_type %d", dist_type);
-  if (N < 0 || M <= 0) return mgp_fail(h, MGP_E_SHAPE, "nearest_center needs N >= 0 and M > 0");
+  if (N < 0 || M <= 0 || M > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "nearest_center needs N >= 0 and 0 < M < 2^31");
   if (N == 0) return MGP_OK;
   if (!X || !Z || !idx) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
   if (k->dtype == MGP_F64)

@@ -100,3 +100,13 @@ if "sweeps" in which:
     V = torch.randn(M, 1, dtype=X.dtype, device=dev)
     ms = timeit(lambda: ops.knm_matvec(k.spec(D), X, Z, V))
     print(f"sweep C4-shard fp32 N={N}: knm {ms:.3f} ms ({N*M/ms/1e6:.2f} Gpair/s)", flush=True)
+if "nearest" in which:
+    for cfg in ["C2", "C3"]:
+        N, D, M, dt, kname = synthetic.CONFIGS[cfg]
+        syn = synthetic.make_inputs(N, D, M, dt)
+        X, Z, y = (torch.from_numpy(a).to(dev) for a in (syn.X, syn.Z, syn.y))
+        k = kernels.SquaredExponential(1.0, [1.0] * D)
+        ms = timeit(lambda: ops.nearest_center(k.spec(D), X, Z, distance_type="sqeuclidean", return_distance=False), reps=5)
+        idx = ops.nearest_center(k.spec(D), X, Z, distance_type="sqeuclidean", return_distance=False)
+        ms2 = timeit(lambda: ops.cluster_stats(idx, y, M), reps=5)
+        print(f"nearest_center {cfg}: {ms:.3f} ms ({N*M/ms/1e6:.0f} Gpair/s); cluster_stats {ms2:.3f} ms", flush=True)
