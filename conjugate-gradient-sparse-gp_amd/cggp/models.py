@@ -418,7 +418,7 @@ class SGPR:
         return self._alpha
 
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
-        assert not full_output_cov and not full_cov, "diagonal predictive variance only"
+        assert not full_output_cov
         iv, kernel = self.inducing_variable, self.kernel
         mean = ops.knm_matvec(kernel.spec(Xnew.shape[1]), Xnew, iv.Z, self.alpha())
         Kms = Kuf(iv, kernel, Xnew)
@@ -429,6 +429,9 @@ class SGPR:
         else:
             W1 = self.conjugate_gradient(self.operator().Kmm, Kms)
         W2 = self.solve_S(Kms)
+        if full_cov:  # GPflow SGPR.predict_f: [1, B, B]
+            cov = kernel.K(Xnew) - Kms.t() @ W1 + self.likelihood.variance * (Kms.t() @ W2)
+            return mean, cov[None, ...]
         var = kernel.K_diag(Xnew) - ops.colwise_dot(Kms, W1) + self.likelihood.variance * ops.colwise_dot(Kms, W2)
         return mean, var[:, None]
 

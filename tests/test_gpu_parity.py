@@ -734,6 +734,9 @@ def test_sgpr_cg_model():
     assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < 1e-5
     e, e0 = m.elbo(), ref.elbo()
     assert abs(e - e0) / abs(e0) < 1e-8
+    _, cov = m.predict_f(T(Xs[:20]), full_cov=True)
+    _, cov0 = ref.predict_f(Xs[:20], full_cov=True)
+    assert cov.shape == (1, 20, 20) and relerr(cov, cov0) < 1e-5
 
 
 @pytest.mark.parametrize("pre,explicit,kmm", [(None, 0, "cg"), ("auto", 0, "cholesky"), (None, 8, "cholesky"),
