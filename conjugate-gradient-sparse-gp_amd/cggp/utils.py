@@ -75,6 +75,70 @@ def load_params(path):
         return {k: f[k] for k in f.files}
 
 
+def store_reference_params(path, params):
+    """Write the reference's own `params.npy` layout (`cggp/utils.py:29-32`: one pickled dict of
+    name -> ndarray inside a 0-d object array) so its `load_from_npy` reads our parameters."""
+    import os
+    import numpy as np
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    np.save(path, {str(k): np.asarray(v) for k, v in params.items()}, allow_pickle=True)
+
+
+def load_reference_params(path):
+    """Read a `params.npy` written by the reference (`np.save(path, dict, allow_pickle=True)`)
+    WITHOUT general unpickling: the `.npy` header is parsed by numpy, and the payload goes through
+    an unpickler whose `find_class` admits only what a dict of plain ndarrays needs (numpy array /
+    dtype / scalar reconstruction, `_codecs.encode`) -- any other global in the stream raises, so
+    nothing from the file is ever called."""
+    import pickle
+    import numpy as np
+
+    allowed = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"),
+    }
+
+    class _ArraysOnly(pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) not in allowed:
+                raise pickle.UnpicklingError(f"refusing {module}.{name}: not a plain-array pickle")
+            if module == "_codecs":
+                import _codecs
+                return _codecs.encode
+            if "multiarray" in module:
+                try:
+                    import numpy._core.multiarray as ma
+                except ImportError:  # numpy < 2
+                    import numpy.core.multiarray as ma
+                return getattr(ma, name)
+            return getattr(np, name)
+
+    with open(path, "rb") as fh:
+        version = np.lib.format.read_magic(fh)
+        if version == (1, 0):
+            shape, _, dtype = np.lib.format.read_array_header_1_0(fh)
+        else:
+            shape, _, dtype = np.lib.format.read_array_header_2_0(fh)
+        if dtype.hasobject:
+            if shape != ():
+                raise ValueError("expected a 0-d object array holding one dict")
+            obj = _ArraysOnly(fh).load()
+        else:
+            raise ValueError("not a pickled parameter dict; use numpy.load for plain arrays")
+    if isinstance(obj, np.ndarray) and obj.dtype.hasobject and obj.shape == ():
+        obj = obj.item()  # np.save pickles the 0-d object array that wraps the dict
+    if not isinstance(obj, dict):
+        raise ValueError("params file does not hold a dict")
+    out = {}
+    for k, v in obj.items():
+        v = np.asarray(v)
+        if v.dtype.hasobject:
+            raise ValueError(f"parameter {k!r} is not a plain array")
+        out[str(k)] = v
+    return out
+
+
 def covariance_properties(model, jitter=0.0, with_lambda=False):
     """Condition-number report (`cggp/paper_cli_uci.py:174-185`; with `with_lambda` the
     `Kuu + Lambda` form of `cggp/paper_condition_wasserstein.py:115-124`).  The symmetric
