@@ -680,6 +680,10 @@ def test_cggp_predict_f(name):
     bmu, bvar = m.predict_f_batched(T(Xs), 100)
     # (the "any" stopping rule makes the step count depend on which rows share a batch)
     assert relerr(bmu, mu.cpu().numpy()) < 1e-9 and relerr(bvar, var.cpu().numpy()) < 1e-6
+    # one CG against the identity shared by all batches == per-batch CG (and the Cholesky twin)
+    smu, svar = m.predict_f_batched(T(Xs), 100, shared_inverse=True)
+    assert relerr(smu, mu.cpu().numpy()) < 1e-9 and relerr(svar, var.cpu().numpy()) < 1e-6
+    assert relerr(svar, tvar0) < 1e-6
     assert relerr(m.q_moments()[0], ref.q_moments()[0]) < 1e-6
     assert relerr(m.diag_variance, ref.diag_variance) < 1e-15
     # the reference's default threshold (cdgp_class, cli_utils.py:439: 1e-6 on 0.5||r||^2): both
