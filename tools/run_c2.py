@@ -29,6 +29,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 mu, var = timed(f"predict_f_batched (all {N} rows, batch {batch})", lambda: model.predict_f_batched(X, batch))
 st = model.conjugate_gradient.last_stats
 print("last batch CG steps:", int(st[0]))
+mu_s, var_s = timed(f"predict_f_batched(shared_inverse=True) (all {N} rows)", lambda: model.predict_f_batched(X, batch, shared_inverse=True))
+print("  inverse CG steps:", int(model.inverse_stats[0]), " max |var diff|", float((var - var_s).abs().max()))
 kl = timed("prior_kl (5 Hutchinson probes)", lambda: model.prior_kl())
 rmse = float(torch.sqrt(((y - mu) ** 2).mean()))
 print("train rmse", rmse, "mean var", float(var.mean()), "kl", kl)
