@@ -427,7 +427,13 @@ def _solve_device(op, rhs, initial_solution, error_threshold, preconditioner, ma
 
 
 class _CGFunction(torch.autograd.Function):
-    """Custom gradient of reference :100-118: db = CG(A, dx) from zero, dA = -solution^T @ db."""
+    """Custom gradient of reference :100-118: db = CG(A, dx) from zero, dA = -solution^T @ db.
+
+    Shortcut (exact): when every row of the incoming `dx` is a multiple of the same row of the
+    forward right-hand side -- `dx_b = c_b rhs_b`, which is what a loss that touches the solution
+    only through `sum(rhs * solution)` sends back (the predictive-variance term `sum(Kmn * W)` of
+    the ELBO, `cggp/models.py:343`) -- then `CG(A, dx)_b = c_b solution_b` and the second solve is
+    skipped.  `conjugate_gradient.backward_shortcuts` counts how often that happened."""
 
     @staticmethod
     def forward(ctx, matrix, rhs, initial_solution, cfg):
@@ -435,16 +441,27 @@ class _CGFunction(torch.autograd.Function):
         sol, stats, err = _solve_device(op, rhs, initial_solution, *cfg)
         ctx.cfg = cfg
         ctx.matrix = matrix
-        ctx.save_for_backward(sol)
+        ctx.zero_start = initial_solution is None
+        ctx.save_for_backward(sol, rhs)
         ctx.mark_non_differentiable(err)
         ctx.stats = stats
         return sol, err
 
     @staticmethod
     def backward(ctx, dx, _derr):
-        (sol,) = ctx.saved_tensors
+        sol, rhs = ctx.saved_tensors
         op = as_operator(ctx.matrix)
-        db, _, _ = _solve_device(op, dx.contiguous(), None, *ctx.cfg)
+        dx = dx.contiguous()
+        db = None
+        if ctx.zero_start:
+            rr = (rhs * rhs).sum(dim=1, keepdim=True)
+            c = (dx * rhs).sum(dim=1, keepdim=True) / torch.where(rr > 0, rr, torch.ones_like(rr))
+            tol = 1e-12 if dx.dtype == torch.float64 else 1e-5
+            if bool(((dx - c * rhs).abs().max() <= tol * dx.abs().max()).item()):
+                db = c * sol
+                conjugate_gradient.backward_shortcuts += 1
+        if db is None:
+            db, _, _ = _solve_device(op, dx, None, *ctx.cfg)
         dA = None
         if isinstance(ctx.matrix, torch.Tensor) and ctx.needs_input_grad[0]:
             dA = -(sol.t() @ db)  # [n,Bt]x[Bt,n] library GEMM (rank-Bt update)
@@ -473,6 +490,7 @@ def conjugate_gradient(matrix, rhs, initial_solution, error_threshold, precondit
 
 
 conjugate_gradient.last_stats = None
+conjugate_gradient.backward_shortcuts = 0
 
 
 class ConjugateGradient:

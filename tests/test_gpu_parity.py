@@ -583,6 +583,28 @@ def test_cg_custom_gradient():
     assert relerr(At.grad, -np.linalg.solve(A, rhs) @ Ainv1.T) < 1e-6
 
 
+def test_cg_custom_gradient_proportional_shortcut():
+    """loss = sum(rhs * CG(A, rhs)): the incoming dx equals rhs, so db = solution without a second
+    solve; gradients equal the closed form d/dB = 2 A^-1 B, d/dA = -(A^-1 B)(A^-1 B)^T."""
+    from cggp.conjugate_gradient import conjugate_gradient
+    A, rhs = cg_problem(n=40, noise=0.1)
+    At = T(A).requires_grad_(True)
+    bt = T(rhs.T).requires_grad_(True)
+    before = conjugate_gradient.backward_shortcuts
+    sol, _ = conjugate_gradient(At, bt, None, 1e-15, max_iterations=400)
+    (3.0 * (sol * bt.detach()).sum()).backward()
+    assert conjugate_gradient.backward_shortcuts == before + 1
+    X = np.linalg.solve(A, rhs)
+    assert relerr(bt.grad, 3.0 * X.T) < 1e-6
+    assert relerr(At.grad, -3.0 * X @ X.T) < 1e-6
+    # a loss that is not of that form takes the second solve
+    At.grad = None
+    sol, _ = conjugate_gradient(At, T(rhs.T), None, 1e-15, max_iterations=400)
+    (sol ** 2).sum().backward()
+    assert conjugate_gradient.backward_shortcuts == before + 1
+    assert relerr(At.grad, -2.0 * X @ np.linalg.solve(A, X).T) < 1e-6
+
+
 def test_eval_logdet():
     """cggp/cg_test.py:49-77: forward 0, backward = d logdet."""
     from cggp.conjugate_gradient import ConjugateGradient

@@ -90,6 +90,30 @@ def test_elbo_gradient_matches_cholesky_twin(name):
         assert abs(g_ls[d] - fd) < 1e-4 * max(1.0, abs(fd)), (d, g_ls[d], fd)
 
 
+def test_fused_solves_equal_solve_by_solve():
+    """One CG over [pseudo_u | Kmn | probes] with the log-det gradient reusing K^-1 Zp gives the same
+    ELBO and the same parameter gradients as the reference's solve-by-solve order (same probes),
+    and with probes = all +-basis columns (P = M) the gradient of the exact branch."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import TrainableCGGP
+    X, y, Z, u, counts = _problem("se")
+    rng = np.random.default_rng(3)
+    probes = T(rng.choice([-1.0, 1.0], size=(Z.shape[0], 6)))
+    out = {}
+    for fused in (True, False):
+        m = TrainableCGGP(kernels.SquaredExponential(1.2, [0.9, 1.4]), 0.15, T(Z),
+                          ConjugateGradient(1e-15, max_iterations=5000), num_probes=6, pseudo_u=T(u),
+                          cluster_counts=T(counts), num_data=X.shape[0], fused_solves=fused)
+        e = m.elbo((T(X[:80]), T(y[:80])), probes=probes)
+        e.backward()
+        out[fused] = (float(e), [p.grad.clone() for p in m.parameters()])
+    # both stop at the reference's guard floor (||r|| ~ 1e-8): agreement to that level
+    assert abs(out[True][0] - out[False][0]) < 1e-7 * abs(out[False][0])
+    for ga, gb in zip(out[True][1], out[False][1]):
+        assert float((ga - gb).abs().max()) < 1e-5 * max(1.0, float(gb.abs().max()))
+
+
 def test_adam_training_reduces_the_loss_and_updates_inducing_parameters():
     from cggp import kernels
     from cggp.conjugate_gradient import ConjugateGradient
