@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle import cg as ocg, cluster as oc, kernels as ok, models as om  # noqa: E402
+from oracle import cg as ocg, cluster as oc, covertree as oct_, kernels as ok, models as om  # noqa: E402
 
 
 def case(name, D, N, M, seed):
@@ -53,7 +53,35 @@ def case(name, D, N, M, seed):
     )
 
 
+def extras(seed=7):
+    """Build-side additions and the F3 cover tree: a preconditioned CG trajectory and a cover tree."""
+    rng = np.random.default_rng(seed)
+    n = 48
+    Xa = rng.standard_normal((n, 2))
+    A = om.add_diagonal(ok.Kernel("se", 1.1, np.array([0.8, 1.2])).K(Xa), 0.05 * np.ones(n))
+    E = rng.standard_normal((n, 6))
+    Pinv = np.linalg.inv(A + 0.1 * E @ E.T)
+    Pinv = 0.5 * (Pinv + Pinv.T)
+    rhs = rng.standard_normal((n, 3))
+    sol6, (_, err6) = ocg.ConjugateGradient(0.0, preconditioner=ocg.DensePreconditioner(Pinv),
+                                            max_iterations=6).solve_with_stats(A, rhs)
+    x = rng.uniform(-3, 3, (600, 2))
+    y = np.sin(x.sum(1, keepdims=True)) + 0.05 * rng.standard_normal((600, 1))
+    tree = oct_.CoverTree((x, y), spatial_resolution=0.6)
+    means, counts = tree.cluster_mean_and_counts
+    leaf_of_row = np.empty(600, dtype=np.int64)
+    for k, rows in enumerate(tree.cluster_rows):
+        leaf_of_row[rows] = k
+    return dict(pcg_A=A, pcg_Pinv=Pinv, pcg_rhs=rhs, pcg_sol_6steps=sol6, pcg_err_6steps=err6,
+                ct_x=x, ct_y=y, ct_resolution=np.array(0.6), ct_level_sizes=np.array([len(lv) for lv in tree.levels]),
+                ct_centroids=tree.centroids, ct_means=means, ct_counts=counts, ct_leaf_of_row=leaf_of_row)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+        np.savez_compressed(os.path.join(HERE, "extras_seed7.npz"), **extras())
+        print("wrote extras")
+        sys.exit(0)
     for name, D, N, M, seed in [("se", 1, 128, 16, 0), ("se", 8, 256, 32, 1), ("matern32", 2, 200, 24, 2),
                                 ("matern52", 3, 160, 20, 3), ("matern12", 2, 150, 16, 4)]:
         np.savez_compressed(os.path.join(HERE, f"{name}_D{D}_N{N}_M{M}.npz"), **case(name, D, N, M, seed))
