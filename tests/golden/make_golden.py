@@ -59,12 +59,12 @@ def extras(seed=7):
     n = 48
     Xa = rng.standard_normal((n, 2))
     A = om.add_diagonal(ok.Kernel("se", 1.1, np.array([0.8, 1.2])).K(Xa), 0.05 * np.ones(n))
-    E = rng.standard_normal((n, 6))
+    E = rng.standard_normal((n, 24))  # rank 24 of 48: far from converged after a few steps
     Pinv = np.linalg.inv(A + 0.1 * E @ E.T)
     Pinv = 0.5 * (Pinv + Pinv.T)
     rhs = rng.standard_normal((n, 3))
-    sol6, (_, err6) = ocg.ConjugateGradient(0.0, preconditioner=ocg.DensePreconditioner(Pinv),
-                                            max_iterations=6).solve_with_stats(A, rhs)
+    sol4, (_, err4) = ocg.ConjugateGradient(0.0, preconditioner=ocg.DensePreconditioner(Pinv),
+                                            max_iterations=4).solve_with_stats(A, rhs)
     x = rng.uniform(-3, 3, (600, 2))
     y = np.sin(x.sum(1, keepdims=True)) + 0.05 * rng.standard_normal((600, 1))
     tree = oct_.CoverTree((x, y), spatial_resolution=0.6)
@@ -72,7 +72,7 @@ def extras(seed=7):
     leaf_of_row = np.empty(600, dtype=np.int64)
     for k, rows in enumerate(tree.cluster_rows):
         leaf_of_row[rows] = k
-    return dict(pcg_A=A, pcg_Pinv=Pinv, pcg_rhs=rhs, pcg_sol_6steps=sol6, pcg_err_6steps=err6,
+    return dict(pcg_A=A, pcg_Pinv=Pinv, pcg_rhs=rhs, pcg_sol_4steps=sol4, pcg_err_4steps=err4,
                 ct_x=x, ct_y=y, ct_resolution=np.array(0.6), ct_level_sizes=np.array([len(lv) for lv in tree.levels]),
                 ct_centroids=tree.centroids, ct_means=means, ct_counts=counts, ct_leaf_of_row=leaf_of_row)
 
