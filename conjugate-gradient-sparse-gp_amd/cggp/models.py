@@ -13,7 +13,7 @@ import torch
 
 from . import ops
 from .conjugate_gradient import ConjugateGradient, SgprNormalOperator, SubsampledNormalPreconditioner
-from .kernels import InducingPoints, Kuf, Kuu, inducingpoint_wrapper
+from .kernels import InducingPoints, Kuf, Kuu, inducingpoint_wrapper  # noqa: F401 (InducingPoints re-exported)
 from .likelihoods import Gaussian
 
 

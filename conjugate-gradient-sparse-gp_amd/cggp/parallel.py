@@ -6,7 +6,6 @@ M-sized CG state are replicated, so every rank runs the identical CG recurrence 
 exchange is one all-reduce(sum) of the [Bt, M] partial product per operator application.
 """
 
-import torch
 import torch.distributed as dist
 
 

@@ -9,7 +9,6 @@ gpflow/kernels/stationaries.py), then GEMV/GEMM against it -- exactly what
 (the cores this process may use: cgroup quota / affinity), as BASELINE.md §3 prescribes.
 """
 
-import os
 import time
 
 import numpy as np
