@@ -406,7 +406,12 @@ class SGPR:
             if pre is None:
                 self._cg_S = cg
             else:
-                self._cg_S = ConjugateGradient(cg.error_threshold, pre, cg.max_iterations, cg.max_steps_cycle,
+                cycle = cg.max_steps_cycle
+                if cycle is None and self.X.dtype != torch.float64:
+                    # below fp64 the preconditioned recurrence drifts from the true residual within
+                    # ~16 steps; the reference's residual refresh (:71-84) every 4 keeps it honest
+                    cycle = 4
+                self._cg_S = ConjugateGradient(cg.error_threshold, pre, cg.max_iterations, cycle,
                                                min_float=cg.min_float, check_every=cg.check_every)
         return self._cg_S
 
