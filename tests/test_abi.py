@@ -56,6 +56,28 @@ def test_null_handle_is_an_error_not_a_crash(lib):
     assert lib.mgp_last_error(None) == b"invalid handle"
 
 
+def test_host_entry_points_validate_arguments(lib):
+    """The cover-tree entry points are host code: bad arguments come back as codes, never a crash."""
+    tree = ctypes.c_void_p()
+    x = (ctypes.c_double * 6)(0, 0, 1, 1, 2, 2)
+    assert lib.mgp_covertree_build(None, 3, 2, 0.0, 2, 1, 1, ctypes.byref(tree)) == -2 and not tree.value
+    assert b"N > 0" in lib.mgp_host_last_error()
+    assert lib.mgp_covertree_build(x, 3, 2, 0.0, 2, 1, 1, None) == -1
+    assert lib.mgp_covertree_build(x, 3, 2, 0.0, 0, 1, 1, ctypes.byref(tree)) == -1  # zero levels
+    assert lib.mgp_covertree_build(x, 3, 2, 100.0, 1, 1, 1, ctypes.byref(tree)) == -1  # resolution > data radius
+    assert lib.mgp_covertree_build(x, 3, 2, 0.0, 2, 1, 1, ctypes.byref(tree)) == 0 and tree.value
+    assert lib.mgp_covertree_num_levels(tree) == 2
+    assert lib.mgp_covertree_level_size(tree, 5) == -1 and lib.mgp_covertree_level_radius(tree, -1) == -1.0
+    assert lib.mgp_covertree_level_nodes(tree, 7, None, None, None) == -1
+    assert lib.mgp_covertree_level_rows(tree, 1, None, None) == -1
+    n = lib.mgp_covertree_level_size(tree, 1)
+    off = (ctypes.c_int64 * (n + 1))()
+    assert lib.mgp_covertree_level_rows(tree, 1, off, None) == 0 and off[n] == 3  # offsets only
+    lib.mgp_covertree_destroy(tree)
+    lib.mgp_covertree_destroy(None)
+    assert lib.mgp_covertree_num_levels(None) == 0
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
 def test_product_path_fails_loudly_without_gpu(lib):
     from cggp import kernels, ops

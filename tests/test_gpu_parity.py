@@ -563,6 +563,33 @@ def test_sgpr_subsampled_preconditioner_fp32():
     assert res < 5e-4 and res < 0.1 * res_eye, (res, res_eye)
 
 
+def test_pcg_abi_rejects_incomplete_preconditioners():
+    """Error convention of the C ABI: a preconditioner struct without its payload is MGP_E_BADARG
+    with a message, the Python shim raises; a mismatched dense inverse is refused before the call."""
+    from cggp import _hip
+    from cggp.conjugate_gradient import (CGPreconditioner, ConjugateGradient, DenseOperator, DensePreconditioner,
+                                         as_operator)
+    A, rhs = cg_problem(n=32, noise=0.1)
+
+    class Broken(CGPreconditioner):
+        def __init__(self, kind):
+            self.kind = kind
+
+        def _native(self, op):
+            st = _hip.MgpPrecond()
+            st.kind = self.kind
+            return st, ()
+
+    for kind in (_hip.PRE_DENSE, _hip.PRE_JACOBI, _hip.PRE_BLOCK, 17):
+        with pytest.raises(RuntimeError, match="preconditioner"):
+            ConjugateGradient(1e-6, preconditioner=Broken(kind))(T(A), T(rhs))
+    with pytest.raises(ValueError):
+        ConjugateGradient(1e-6, preconditioner=DensePreconditioner(T(np.eye(31))))(T(A), T(rhs))
+    with pytest.raises(ValueError):
+        DensePreconditioner(T(np.ones((4, 5))))
+    assert isinstance(as_operator(T(A)), DenseOperator)
+
+
 def test_cg_fp32():
     from cggp.conjugate_gradient import ConjugateGradient
     A, rhs = cg_problem(n=80, noise=0.5)
