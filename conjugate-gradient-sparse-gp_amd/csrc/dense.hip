@@ -386,7 +386,21 @@ inline bool gemm_vec_ok(const T* P, long ldp, const T* A, long lda, long K) {
   return (K % 16) == 0 && ((ldp | lda) % (16 / (long)sizeof(T))) == 0 && ((((uintptr_t)P) | ((uintptr_t)A)) % 16) == 0;
 }
 
-// out[m, n] (+)= P[m,K] . A[n,K]^T : picks the 64x64 tile when 128x128 tiles would not fill the CUs
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_slices_sum_kernel(const T* __restrict__ part, long tot, int nz,
+                                                              T* __restrict__ out, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= tot) return;
+  T s = part[e];
+  for (int z = 1; z < nz; ++z) s += part[(long)z * tot + e];  // slice order: deterministic
+  out[e] = s;
+}
+
+// out[m, n] (+)= P[m,K] . A[n,K]^T.  Shape policy: 128x128 tiles when they fill the CUs twice over;
+// otherwise, when the contraction is long enough, 128x128 tiles x nz slices of K (each slice its own
+// partial output, summed in slice order) so that the throughput tile still sees >= 2 workgroups per
+// CU; otherwise 64x64 tiles.
 template <typename T>
 int gemm_nt_launch(mgp_handle* h, const T* P, long ldp, long m, const T* A, long lda, long n, long K, T* out,
                    long ldo, int accumulate, const int* gate) {
@@ -402,8 +416,23 @@ int gemm_nt_launch(mgp_handle* h, const T* P, long ldp, long m, const T* A, long
     if (vec) MGP_GEMM(true, 4);
     else MGP_GEMM(false, 4);
   } else {
-    if (vec) MGP_GEMM(true, 2);
-    else MGP_GEMM(false, 2);
+    long nz = (2L * h->num_cus + big - 1) / big;
+    if (nz > 8) nz = 8;
+    while (nz > 1 && (K % (16 * nz) != 0 || K / nz < 256)) --nz;  // slices stay 16-aligned and worth a launch
+    if (h->gemm_ksplit && nz > 1 && vec && !accumulate && ldo == n) {
+      const long tot = m * n;
+      MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nz * tot * sizeof(T)));
+      T* part = (T*)h->ws;
+      dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), (unsigned)nz);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, true, 4>), grid, dim3(256), 0, h->stream, P, ldp, m, A, lda, n, K / nz,
+                         part, n, 0, 0, gate, K / nz, tot, (const int*)nullptr, 0);
+      MGP_LAUNCH_CHECK(h);
+      hipLaunchKernelGGL((gemm_slices_sum_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                         (const T*)part, tot, (int)nz, out, gate);
+    } else {
+      if (vec) MGP_GEMM(true, 2);
+      else MGP_GEMM(false, 2);
+    }
   }
 #undef MGP_GEMM
   MGP_LAUNCH_CHECK(h);
