@@ -122,6 +122,24 @@ def k_dense_vjp(spec, A, B, G):
     return dvar.value, [dls[d] for d in range(spec.D)]
 
 
+def kmm_lambda_matvec(spec, Z, lam, V):
+    """out [R,M] = V [R,M] @ (k(Z,Z) + diag(lam)), matrix-free (row M2)."""
+    Z = _points(Z, "Z", spec.D)
+    M = Z.shape[0]
+    lam = _hip.check_tensor(lam, "lam", dtype=Z.dtype, shape=(M,))
+    V = _hip.check_tensor(V, "V", dtype=Z.dtype)
+    if V.dim() != 2 or V.shape[1] != M:
+        raise ValueError(f"V must be [R, M={M}], got {tuple(V.shape)}")
+    out = torch.empty_like(V)
+    if V.shape[0] == 0 or M == 0:
+        return out
+    hd = _hip.get_handle(Z.device)
+    k = spec.struct(_hip.dtype_code(Z))
+    hd.check(hd.lib.mgp_kmm_lambda_matvec(hd.h, ctypes.byref(k), _hip.ptr(Z), M, _hip.ptr(lam), _hip.ptr(V),
+                                          V.shape[0], _hip.ptr(out)))
+    return out
+
+
 def kmn_knm(spec, X, Z):
     """out [M,M] = k(Z,X) k(X,Z) on the matrix cores (row S1)."""
     X = _points(X, "X", spec.D)

@@ -594,3 +594,21 @@ extern "C" int mgp_operator_apply(mgp_handle* h, const mgp_operator* op, const v
   if (op->dtype == MGP_F64) return apply_operator<double>(h, op, (const double*)P, Bt, (double*)out, nullptr);
   return apply_operator<float>(h, op, (const float*)P, Bt, (float*)out, nullptr);
 }
+
+// Named form of the matrix-free (Kmm + Lambda) product (SURVEY 8b lists it as its own entry point):
+// out[R, M] = V[R, M] @ (k(Z, Z) + diag(lambda)), rows = right-hand sides, nothing M x M materialised.
+extern "C" int mgp_kmm_lambda_matvec(mgp_handle* h, const mgp_kernel* k, const void* Z, int64_t M,
+                                     const void* lambda, const void* V, int64_t R, void* out) {
+  if (!h) return MGP_E_BADARG;
+  MGP_TRY(mgp_check_kernel(h, k));
+  mgp_operator op;
+  memset(&op, 0, sizeof(op));
+  op.kind = MGP_OP_KMM_LAMBDA;
+  op.dtype = k->dtype;
+  op.n = M;
+  op.kernel = k;
+  op.Z = Z;
+  op.M = M;
+  op.lambda = lambda;
+  return mgp_operator_apply(h, &op, V, R, out);
+}

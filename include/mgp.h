@@ -168,6 +168,10 @@ int mgp_pcg_solve(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre,
                   void* err_out, mgp_cg_stats* stats);
 /* one application of an operator: out[Bt,n] = P[Bt,n] @ Op (used by tests and the bench) */
 int mgp_operator_apply(mgp_handle* h, const mgp_operator* op, const void* P, int64_t Bt, void* out);
+/* the matrix-free (Kmm + Lambda) product by name (row M2, `p @ A` with A = add_diagonal(Kuu, lambda),
+ * models.py:301,337): out[R,M] = V[R,M] @ (k(Z,Z) + diag(lambda)); lambda [M] on the device */
+int mgp_kmm_lambda_matvec(mgp_handle* h, const mgp_kernel* k, const void* Z, int64_t M, const void* lambda,
+                          const void* V, int64_t R, void* out);
 
 /* ---- reductions used by the model surface ----------------------------------------------
  * out[c] = sum_r A[r,c]*B[r,c] (axis 0, like tf.reduce_sum(Kmn * W, axis=0), models.py:343) */

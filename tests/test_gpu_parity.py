@@ -316,6 +316,18 @@ def test_symm_matmul_asymmetric_b_layout_check():
     assert np.array_equal(out.cpu().numpy(), P)
 
 
+@pytest.mark.parametrize("name,D,R", [("se", 8, 1), ("matern32", 2, 5), ("matern52", 3, 70)])
+def test_kmm_lambda_matvec(name, D, R):
+    from cggp import ops
+    k, ko = make_kernel(name, D)
+    rng = np.random.default_rng(21)
+    Z = rng.standard_normal((300, D))
+    lam = rng.uniform(0.01, 0.5, 300)
+    V = rng.standard_normal((R, 300))
+    out = ops.kmm_lambda_matvec(k.spec(D), T(Z), T(lam), T(V))
+    assert relerr(out, V @ (ko.K(Z) + np.diag(lam))) < 1e-11
+
+
 # ------------------------------------------------------------------ contraction
 @pytest.mark.parametrize("name,D", [("se", 8), ("matern32", 32), ("matern12", 3)])
 def test_kmn_knm(name, D):
