@@ -191,7 +191,11 @@ def main():
         from cggp.conjugate_gradient import SubsampledNormalPreconditioner
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=16, seed=0)
+        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
+        torch.cuda.synchronize()
+        t_build_cold = time.perf_counter() - tb  # includes the one-off load of the factorisation library
+        tb = time.perf_counter()
+        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
         torch.cuda.synchronize()
         t_build = time.perf_counter() - tb
         tc = time.perf_counter()
@@ -204,8 +208,9 @@ def main():
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - tc
         rres = rhs_rows - op.rmatmul(sol)
-        pcg = {"preconditioner": "SubsampledNormalPreconditioner(rows_per_inducing=16)",
-               "sample_rows": pre.sample_rows, "build_seconds": t_build, "error_threshold": 1e-6,
+        pcg = {"preconditioner": "SubsampledNormalPreconditioner(rows_per_inducing=32)",
+               "sample_rows": pre.sample_rows, "build_seconds": t_build, "build_seconds_first_call": t_build_cold,
+               "error_threshold": 1e-6,
                "iteration_cap": pcap, "max_steps_cycle": pcycle, "iterations": int(steps), "converged": bool(int(steps) < pcap),
                "solve_seconds": t_solve,
                "half_rz_final": float(err.max().item()),
