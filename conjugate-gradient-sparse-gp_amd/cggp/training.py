@@ -226,3 +226,62 @@ def train_using_adam_and_update(data, model, iterations, batch_size, learning_ra
         if monitor is not None:
             monitor(iteration)
     return losses
+
+
+def train_using_lbfgs_and_update(data, model, max_num_iters, update_fn=None, update_during_training=None,
+                                 monitor=None, probe_seed=0):
+    """`cggp/optimize.py:152-195`: full-batch L-BFGS (scipy `L-BFGS-B`, what `gpflow.optimizers.Scipy`
+    drives) over the model's trainable parameters; `update_fn` / `monitor` are called before the
+    first step and after every accepted step, as the reference's `step_callback`.
+
+    L-BFGS needs a deterministic objective, so when the model estimates the trace / log-det terms
+    with Hutchinson probes the SAME probes (drawn once from `probe_seed`) are used for every
+    evaluation.  Returns scipy's `OptimizeResult` (None when `max_num_iters` is 0, as upstream)."""
+    from scipy.optimize import minimize
+
+    params = model.parameters()
+    sizes = [p.numel() for p in params]
+    x, y = data
+    probes = None
+    if model.num_probes is not None:
+        probes = rademacher((model.Z.shape[0], model.num_probes), model.Z.dtype, model.Z.device, probe_seed)
+
+    def assign(flat):
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(params, sizes):
+                p.copy_(torch.from_numpy(flat[off:off + n].copy()).reshape(p.shape))
+                off += n
+
+    def value_and_grad(flat):
+        assign(flat)
+        for p in params:
+            p.grad = None
+        loss = model.training_loss((x, y), probes=probes)
+        loss.backward()
+        g = np.concatenate([p.grad.detach().cpu().numpy().reshape(-1) for p in params])
+        return float(loss), g.astype(np.float64)
+
+    state = {"iteration": 0}
+
+    def internal_update_fn(iteration):
+        if update_during_training and (update_fn is not None):
+            update_fn()
+        if monitor is not None:
+            monitor(iteration)
+
+    def callback(_xk):
+        state["iteration"] += 1
+        internal_update_fn(state["iteration"])
+
+    internal_update_fn(0)
+    if max_num_iters > 0:
+        x0 = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in params]).astype(np.float64)
+        result = minimize(value_and_grad, x0, jac=True, method="L-BFGS-B", callback=callback,
+                          options=dict(maxiter=int(max_num_iters)))
+        assign(result.x)
+        return result
+    internal_update_fn(-1)
+    if monitor is not None and hasattr(monitor, "close"):
+        monitor.close()
+    return None

