@@ -62,3 +62,50 @@ def assign_inducing_parameters(model, iv, means, counts):
         model.pseudo_u = means.to(model.pseudo_u.dtype)
         model.cluster_counts = counts.to(model.cluster_counts.dtype)
     return iv, means, counts
+
+
+def make_param_callback(model):
+    """`optimize.py:267-282`: kernel / likelihood parameters keyed as the reference logs them."""
+    def _callback(*args, **kwargs):
+        k, lik = model.kernel, model.likelihood
+        return {"kernel/variance": np.asarray(k.variance, dtype=np.float64),
+                "kernel/lengthscales": np.asarray(k.lengthscales, dtype=np.float64),
+                "likelihood/variance": np.asarray(lik.variance, dtype=np.float64)}
+    return _callback
+
+
+def make_metrics_callback(model, train_data, test_data, batch_size, use_jit=True, print_on=True,
+                          check_numerics=True):
+    """`optimize.py:285-364`: a `step_callback(step)` returning `{"train/elbo", "test/rmse",
+    "test/nlpd"}` -- test error and log predictive density accumulated over batches of
+    `batch_size`, the training ELBO summed over training batches (models with internal data: one
+    `elbo()` call)."""
+    import json
+    import math
+
+    def step_callback(step, *args, **kwargs):
+        x, y = test_data
+        sq, lpd, n = 0.0, 0.0, 0
+        for s in range(0, x.shape[0], batch_size):
+            xb, yb = x[s:s + batch_size], y[s:s + batch_size]
+            mu, var = model.predict_f(xb)
+            lpd += float(model.likelihood.predict_log_density(xb, mu, var, yb).sum())
+            sq += float(((yb - mu) ** 2).sum())
+            n += xb.shape[0]
+        import inspect
+        if len(inspect.signature(model.elbo).parameters) == 0:  # internal-data models (SGPR)
+            elbo = float(model.elbo())
+        else:
+            xt, yt = train_data
+            elbo = 0.0
+            for s in range(0, xt.shape[0], batch_size):
+                elbo += float(model.elbo((xt[s:s + batch_size], yt[s:s + batch_size])))
+        metrics = {"train/elbo": float(elbo), "test/rmse": math.sqrt(sq / n), "test/nlpd": -lpd / n}
+        if print_on:
+            fmt = {k: np.format_float_scientific(v, precision=4) for k, v in metrics.items()}
+            print(f"Step [{step}], metrics: {json.dumps(fmt)}")
+        if check_numerics and not math.isfinite(elbo):
+            raise FloatingPointError(f"The training ELBO has got an undefined value {elbo}")
+        return metrics
+
+    return step_callback

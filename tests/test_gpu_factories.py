@@ -104,3 +104,33 @@ def test_name_to_kernel_and_errors():
         cli_utils.create_update_fn("spectral", None, (T(X), T(y)))
     with pytest.raises(ValueError):
         cli_utils.create_uniform_update_fn(None, (T(X), T(y)), max_points=500)
+
+
+def test_metrics_and_param_callbacks():
+    """`make_metrics_callback` / `make_param_callback` (optimize.py:267-364) against the oracle's
+    closed forms on the same model."""
+    from cggp import cli_utils
+    from cggp.optimize import make_metrics_callback, make_param_callback
+    X, y = data(1200)
+    Xt, yt = T(X[:1000]), T(y[:1000])
+    Xs, ys = T(X[1000:]), T(y[1000:])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, update_fn = cli_utils.create_model_and_update_fn(
+            lambda *a, **k: cli_utils.cdgp_class(*a, error_threshold=1e-13, num_probes=None, **k), (Xt, yt), "oips",
+            model_kwargs=dict(num_inducing_points=30), clustering_kwargs=dict(rho=0.7, max_points=200))
+        iv, means, counts = update_fn()
+    cb = make_metrics_callback(model, (Xt, yt), (Xs, ys), batch_size=128, print_on=False)
+    m = cb(3)
+    ko = ok.Kernel("matern32", 1.0, np.ones(2))
+    ref = om.CGGP(ko, 0.1, iv.cpu().numpy(), ocg.ConjugateGradient(1e-13, max_iterations=5000), num_probes=None,
+                  pseudo_u=means.cpu().numpy(), cluster_counts=counts.cpu().numpy(), num_data=1000)
+    mu0, var0 = ref.predict_f(X[1000:])
+    r0, n0 = om.rmse_nlpd(mu0, var0, y[1000:], 0.1)
+    assert abs(m["test/rmse"] - r0) < 1e-6 * r0 and abs(m["test/nlpd"] - n0) < 1e-6 * abs(n0)
+    Xtr, ytr = X[:1000], y[:1000]
+    e0 = sum(ref.elbo((Xtr[s:s + 128], ytr[s:s + 128])) for s in range(0, 1000, 128))
+    assert abs(m["train/elbo"] - e0) < 1e-6 * abs(e0)
+    p = make_param_callback(model)()
+    assert float(p["kernel/variance"]) == 1.0 and list(p["kernel/lengthscales"]) == [1.0, 1.0]
+    assert abs(float(p["likelihood/variance"]) - 0.1) < 1e-15
