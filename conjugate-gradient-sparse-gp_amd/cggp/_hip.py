@@ -104,6 +104,7 @@ SIGNATURES = {
     "mgp_nearest_center": (_I, [_P, _KP, _I, _P, _L, _P, _L, _P, _P]),
     "mgp_cluster_stats": (_I, [_P, _I, _P, _P, _L, _L, _P, _P]),
     "mgp_k_dense_vjp": (_I, [_P, _KP, _P, _L, _P, _L, _P, _L, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
+    "mgp_segment_sums": (_I, [_P, _I, _P, _P, _P, _L, _L, _L, _P]),
     "mgp_kmm_lambda_matvec": (_I, [_P, _KP, _P, _L, _P, _P, _L, _P]),
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),

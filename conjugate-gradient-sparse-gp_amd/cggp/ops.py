@@ -232,15 +232,47 @@ def nearest_center(spec, X, Z, distance_type="sqeuclidean", return_distance=True
     return (idx, best) if return_distance else idx
 
 
-def cluster_stats(idx, y, M):
-    """(sums [M], counts [M]) of y per cluster, deterministic order."""
+def cluster_stats(idx, y, M, method="auto"):
+    """(sums, counts [M]) of y per cluster, deterministic order.  y [N] -> sums [M]; y [N,C] ->
+    sums [M,C].
+
+    "sweep": the fused N x M transpose sweep (`mgp_cluster_stats`, one column per launch).
+    "sorted": group the rows by cluster with one stable device sort, then `mgp_segment_sums` --
+    N C work instead of N M C.  "auto" takes the sort once N M exceeds 2^29 pairs (C3: 0.40 ms vs
+    0.93 ms; C2, 2e8 pairs: 0.21 vs 0.09 ms) or several columns are asked for (C3, 8 columns: 0.55 ms
+    vs 7.4 ms)."""
     idx = _hip.check_tensor(idx, "idx", dtype=torch.int64).reshape(-1)
-    y = _hip.check_tensor(y, "y").reshape(-1)
-    if idx.shape[0] != y.shape[0]:
+    y = _hip.check_tensor(y, "y")
+    multi = y.dim() == 2 and y.shape[1] > 1
+    Y = y if multi else y.reshape(-1, 1)
+    N, C = Y.shape
+    if idx.shape[0] != N:
         raise ValueError("idx / y length mismatch")
-    sums = torch.empty((M,), dtype=y.dtype, device=y.device)
-    counts = torch.empty((M,), dtype=y.dtype, device=y.device)
+    if method == "auto":
+        method = "sorted" if (C > 1 or N * M > (1 << 29)) else "sweep"
     hd = _hip.get_handle(y.device)
-    hd.check(hd.lib.mgp_cluster_stats(hd.h, _hip.dtype_code(y), _hip.ptr(idx), _hip.ptr(y), y.shape[0], M,
-                                      _hip.ptr(sums), _hip.ptr(counts)))
-    return sums, counts
+    if method == "sweep":
+        cols, counts = [], None
+        for c in range(C):
+            sums = torch.empty((M,), dtype=y.dtype, device=y.device)
+            counts = torch.empty((M,), dtype=y.dtype, device=y.device)
+            col = Y[:, c].contiguous()
+            hd.check(hd.lib.mgp_cluster_stats(hd.h, _hip.dtype_code(y), _hip.ptr(idx), _hip.ptr(col), N, M,
+                                              _hip.ptr(sums), _hip.ptr(counts)))
+            cols.append(sums)
+        sums = torch.stack(cols, dim=1)
+    elif method == "sorted":
+        if N and (int(idx.min()) < 0 or int(idx.max()) >= M):
+            raise ValueError("cluster index out of range")
+        order = torch.argsort(idx, stable=True)
+        cnt = torch.bincount(idx, minlength=M)
+        offsets = torch.zeros((M + 1,), dtype=torch.int64, device=idx.device)
+        torch.cumsum(cnt, dim=0, out=offsets[1:])
+        sums = torch.empty((M, C), dtype=y.dtype, device=y.device)
+        Yc = Y.contiguous()
+        hd.check(hd.lib.mgp_segment_sums(hd.h, _hip.dtype_code(y), _hip.ptr(order), _hip.ptr(offsets), _hip.ptr(Yc),
+                                         N, C, M, _hip.ptr(sums)))
+        counts = cnt.to(y.dtype)
+    else:
+        raise ValueError(f"unknown method {method!r}")
+    return (sums if multi else sums[:, 0].contiguous()), counts

@@ -32,18 +32,15 @@ def kmeans_lloyd(points, k_centroids, threshold=1e-5, initial_centroids=None, di
     if initial_centroids is None:  # :65-67
         g = torch.Generator().manual_seed(seed)
         initial_centroids = points[torch.randperm(points.shape[0], generator=g)[:k_centroids].to(points.device)]
-    D = points.shape[1]
-    cols = [points[:, d].contiguous() for d in range(D)]
 
     def body(centroids):
         idx, dist = kmeans_indices_and_distances(centroids, points, distance_type, kernel)  # :48-50
-        sums, counts = [], None
-        for d in range(D):  # per-cluster coordinate sums, deterministic order (:58-63)
-            s, c = ops.cluster_stats(idx, cols[d], k_centroids)
-            sums.append(s)
-            counts = c
+        # per-cluster coordinate sums in one pass, deterministic order (:58-63)
+        sums, counts = ops.cluster_stats(idx, points, k_centroids)
+        if sums.dim() == 1:  # one input dimension
+            sums = sums[:, None]
         counts = torch.clamp(counts, min=1.0)  # :55
-        return torch.stack(sums, dim=1) / counts[:, None], float(dist.mean())
+        return sums / counts[:, None], float(dist.mean())
 
     centroids, mean_d = body(initial_centroids.contiguous())  # :70
     prev, loops = float("inf"), 1

@@ -216,7 +216,46 @@ int cluster_stats_t(mgp_handle* h, const long* idx, const T* y, long N, long M, 
   return MGP_OK;
 }
 
+// Segmented column sums of rows already grouped by cluster (order[] = stable sort of the rows by
+// cluster, offsets[m] .. offsets[m+1] = the rows of cluster m): one wave per (cluster, column
+// block), lanes stride the segment in order, fixed butterfly at the end -- deterministic, and
+// N C work instead of the N M C of the transpose sweep.
+template <typename T>
+__global__ __launch_bounds__(256) void segment_sums_kernel(const long* __restrict__ order,
+                                                           const long* __restrict__ offsets,
+                                                           const T* __restrict__ Y, long C, long M,
+                                                           T* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long lo = offsets[m], hi = offsets[m + 1];
+  for (long c = 0; c < C; ++c) {
+    T s = 0;
+    for (long i = lo + lane; i < hi; i += 64) s += Y[order[i] * C + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) sums[m * C + c] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int mgp_segment_sums(mgp_handle* h, int dtype, const int64_t* order, const int64_t* offsets,
+                                const void* Y, int64_t N, int64_t C, int64_t M, void* sums) {
+  if (!h) return MGP_E_BADARG;
+  if (dtype != MGP_F32 && dtype != MGP_F64) return mgp_fail(h, MGP_E_DTYPE, "bad dtype %d", dtype);
+  if (N < 0 || M <= 0 || C <= 0) return mgp_fail(h, MGP_E_SHAPE, "segment_sums: bad shape");
+  if (!offsets || !sums || (N > 0 && (!order || !Y))) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (dtype == MGP_F64)
+    hipLaunchKernelGGL((segment_sums_kernel<double>), grid, dim3(256), 0, h->stream, (const long*)order,
+                       (const long*)offsets, (const double*)Y, (long)C, (long)M, (double*)sums);
+  else
+    hipLaunchKernelGGL((segment_sums_kernel<float>), grid, dim3(256), 0, h->stream, (const long*)order,
+                       (const long*)offsets, (const float*)Y, (long)C, (long)M, (float*)sums);
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
 
 extern "C" int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const void* X, int64_t N,
                                   const void* Z, int64_t M, int64_t* idx, void* best) {

@@ -189,6 +189,12 @@ int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const 
                        const void* Z, int64_t M, int64_t* idx, void* best);
 int mgp_cluster_stats(mgp_handle* h, int dtype, const int64_t* idx, const void* y, int64_t N,
                       int64_t M, void* sums, void* counts);
+/* the same sums for C columns at once when the caller has grouped the rows: order [N] = row indices
+ * sorted (stably) by cluster, offsets [M+1] = start of every cluster's run in `order`;
+ * sums[M,C] = per-cluster column sums of Y [N,C], summed in a fixed order (N C work, against the
+ * N M of the sweep above: the k-means centroid update, selection.py:58-63, and optimize.py:61-78) */
+int mgp_segment_sums(mgp_handle* h, int dtype, const int64_t* order, const int64_t* offsets, const void* Y,
+                     int64_t N, int64_t C, int64_t M, void* sums);
 
 /* ---- next row F2: hyper-parameter gradient of a kernel block ---------------------------------
  * Given G = dL/dK for K = k(A,B) [na, nb] (leading dimension ldg), returns (host doubles)

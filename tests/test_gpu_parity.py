@@ -825,6 +825,30 @@ def test_sgpr_solve_paths(pre, explicit, kmm):
         assert steps < 40, steps  # the identity-preconditioned solve takes hundreds here
 
 
+@pytest.mark.parametrize("N,M,C", [(5000, 37, 1), (5000, 37, 4), (100, 300, 3), (70000, 512, 2)])
+def test_cluster_stats_sorted_and_sweep_agree(N, M, C):
+    """The two forms of the per-cluster sums (fused N x M sweep, and stable sort + segmented sums)
+    against the oracle: counts exact, sums to rounding, both deterministic run to run."""
+    from cggp import ops
+    rng = np.random.default_rng(N + M)
+    idx = rng.integers(0, M, N)
+    idx[idx == 3] = 4  # an empty cluster
+    Y = rng.standard_normal((N, C))
+    ref = np.zeros((M, C))
+    np.add.at(ref, idx, Y)
+    cnt = np.bincount(idx, minlength=M).astype(np.float64)
+    it = torch.from_numpy(idx).to("cuda:0")
+    for method in ("sweep", "sorted", "auto"):
+        sums, counts = ops.cluster_stats(it, T(Y if C > 1 else Y[:, 0]), M, method=method)
+        assert sums.shape == ((M, C) if C > 1 else (M,))
+        assert np.array_equal(counts.cpu().numpy(), cnt)
+        assert relerr(sums.reshape(M, C), ref) < 1e-12
+        again, _ = ops.cluster_stats(it, T(Y if C > 1 else Y[:, 0]), M, method=method)
+        assert torch.equal(sums, again)
+    with pytest.raises(ValueError):
+        ops.cluster_stats(it + M, T(Y), M, method="sorted")
+
+
 # ------------------------------------------------------------------ F1: assignment + stats
 @pytest.mark.parametrize("dist", ["sqeuclidean", "euclidean", "covariance", "correlation"])
 def test_nearest_center(dist):

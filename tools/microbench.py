@@ -108,5 +108,8 @@ if "nearest" in which:
         k = kernels.SquaredExponential(1.0, [1.0] * D)
         ms = timeit(lambda: ops.nearest_center(k.spec(D), X, Z, distance_type="sqeuclidean", return_distance=False), reps=5)
         idx = ops.nearest_center(k.spec(D), X, Z, distance_type="sqeuclidean", return_distance=False)
-        ms2 = timeit(lambda: ops.cluster_stats(idx, y, M), reps=5)
-        print(f"nearest_center {cfg}: {ms:.3f} ms ({N*M/ms/1e6:.0f} Gpair/s); cluster_stats {ms2:.3f} ms", flush=True)
+        ms2 = timeit(lambda: ops.cluster_stats(idx, y, M, method="sweep"), reps=5)
+        ms3 = timeit(lambda: ops.cluster_stats(idx, y, M, method="sorted"), reps=5)
+        ms4 = timeit(lambda: ops.cluster_stats(idx, X, M, method="sorted"), reps=5)
+        print(f"nearest_center {cfg}: {ms:.3f} ms ({N*M/ms/1e6:.0f} Gpair/s); cluster_stats sweep {ms2:.3f} ms, "
+              f"sorted {ms3:.3f} ms, sorted with {D} columns {ms4:.3f} ms", flush=True)
