@@ -333,6 +333,24 @@ class CGGP(ClusterGP):
         var_exp = self.likelihood.variational_expectations(x, f_mean, f_var, y)
         return var_exp.sum().item() * self.scale(x.shape[0]) - kl
 
+    def elbo_over_batches(self, data, batch_size, shared_inverse=True, probes=None):
+        """sum_b elbo(batch_b) -- the quantity `make_metrics_callback` accumulates as "train/elbo"
+        (`cggp/optimize.py:336-338`) -- without repeating the batch-independent work: the prior KL is
+        evaluated once and counted once per batch, and the predictive moments of all rows come from
+        `predict_f_batched` (with `shared_inverse`: one M-column CG for the whole data set instead of
+        one B-column CG per batch).  With Hutchinson probes the reference draws fresh probes in every
+        batch's KL; here the one evaluation stands for all of them."""
+        x, y = data
+        kl = self.prior_kl(probes=probes)
+        mu, var = self.predict_f_batched(x, batch_size, shared_inverse=shared_inverse)
+        ve = self.likelihood.variational_expectations(x, mu, var, y)
+        total, nb = 0.0, 0
+        for s in range(0, x.shape[0], batch_size):
+            part = ve[s:s + batch_size]
+            total += part.sum().item() * self.scale(part.shape[0])
+            nb += 1
+        return total - nb * kl
+
     def logdet_gradient(self, df=1.0, probes=None):
         """d/dK of the omitted log|Kmm+Lambda| term (`eval_logdet` backward, row M5)."""
         _, KmmLambda = self._Kmm_and_KmmLambda()

@@ -95,6 +95,8 @@ def make_metrics_callback(model, train_data, test_data, batch_size, use_jit=True
         import inspect
         if len(inspect.signature(model.elbo).parameters) == 0:  # internal-data models (SGPR)
             elbo = float(model.elbo())
+        elif hasattr(model, "elbo_over_batches"):  # same sum, batch-independent solves done once
+            elbo = float(model.elbo_over_batches(train_data, batch_size))
         else:
             xt, yt = train_data
             elbo = 0.0

@@ -131,6 +131,9 @@ def test_metrics_and_param_callbacks():
     Xtr, ytr = X[:1000], y[:1000]
     e0 = sum(ref.elbo((Xtr[s:s + 128], ytr[s:s + 128])) for s in range(0, 1000, 128))
     assert abs(m["train/elbo"] - e0) < 1e-6 * abs(e0)
+    direct = sum(float(model.elbo((Xt[s:s + 128], yt[s:s + 128]))) for s in range(0, 1000, 128))
+    assert abs(model.elbo_over_batches((Xt, yt), 128, shared_inverse=False) - direct) < 1e-8 * abs(direct)
+    assert abs(model.elbo_over_batches((Xt, yt), 128, shared_inverse=True) - direct) < 1e-7 * abs(direct)
     p = make_param_callback(model)()
     assert float(p["kernel/variance"]) == 1.0 and list(p["kernel/lengthscales"]) == [1.0, 1.0]
     assert abs(float(p["likelihood/variance"]) - 0.1) < 1e-15
