@@ -26,6 +26,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (nz && atoi(nz) > 0 && atoi(nz) <= 64) h->contract_nz = atoi(nz);
   const char* gk = getenv("MGP_GEMM_KSPLIT");
   if (gk && strcmp(gk, "0") == 0) h->gemm_ksplit = 0;
+  const char* sb = getenv("MGP_SKINNY_BPC");
+  if (sb && atoi(sb) > 0 && atoi(sb) <= 8) h->skinny_blocks_per_cu = atoi(sb);
   const char* sk = getenv("MGP_SKINNY");
   if (sk && strcmp(sk, "reg") == 0) h->skinny_mode = 0;
   const char* tm = getenv("MGP_TRI_MIN_N");

@@ -44,6 +44,7 @@ struct mgp_handle {
   // row-streaming GEMV (MGP_TRI_MIN_N)
   long tri_min_n = 1024;
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
+  int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
   int skinny_mode = 1;  // 2 <= Bt <= 128 product: 1 = P staged through LDS, 0 = register operands (MGP_SKINNY=reg)
   int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)
