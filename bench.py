@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1 only: run the all-reduce hook on a 1-rank group (measures its fixed per-step cost)")
     ap.add_argument("--rows", type=int, default=0, help="override the TOTAL row count (0 = the config's)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): the config's N is the TOTAL row count, sharded over the ranks -- the "
+                         "size BASELINE.json's metric is quoted on; weak: every rank holds the config's N rows")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout (RCCL prints a version banner there): park fd 1 on stderr
@@ -88,6 +91,8 @@ def main():
     N, D, M, dtype_name, kname = synthetic.CONFIGS[args.config]
     if args.rows:
         N = args.rows
+    if args.scaling == "weak":
+        N = N * world  # per-GPU work fixed: the job grows with the number of ranks
     tdtype = torch.float64 if dtype_name == "float64" else torch.float32
     esize = 8 if dtype_name == "float64" else 4
     syn = synthetic.make_inputs(N, D, M, dtype_name)
@@ -271,8 +276,9 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "CG iters/sec (matrix-free SGPR-CG, N=2^20 M=4096 D=8 fp64)" if args.config == "C3"
-                      else f"CG iters/sec ({args.config})",
+            "metric": "CG iters/sec (matrix-free SGPR-CG, N=2^20 M=4096 D=8 fp64)"
+                      if args.config == "C3" and not args.rows and (args.scaling == "strong" or world == 1)
+                      else f"CG iters/sec ({args.config}, N={N} total)",
             "value": args.steps / elapsed,
             "unit": "CG iters/s",
             "n_gpus": world,
@@ -280,7 +286,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64" if esize == 8 else "f32",
             "data": "synthetic",
