@@ -1,0 +1,139 @@
+"""Property tests (hypothesis), the fourth pin of SURVEY 8c: kernel matrices are symmetric, positive
+semi-definite with k(x,x) = variance; the transpose product is shard-sum invariant; and -- on the
+GPU -- randomly shaped (ragged, tiny, odd) problems through every fused entry point against the
+oracle, which is where indexing mistakes live."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import cg as ocg, cluster as oc, kernels as ok
+
+KINDS = ["se", "matern12", "matern32", "matern52"]
+COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+@st.composite
+def kernel_case(draw, max_n=60, max_m=40, max_d=6):
+    D = draw(st.integers(1, max_d))
+    N = draw(st.integers(1, max_n))
+    M = draw(st.integers(1, max_m))
+    name = draw(st.sampled_from(KINDS))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    ls = rng.uniform(0.3, 3.0, D)
+    var = float(rng.uniform(0.2, 4.0))
+    X = rng.standard_normal((N, D)) * draw(st.sampled_from([0.1, 1.0, 3.0]))
+    Z = rng.standard_normal((M, D))
+    return name, var, ls, X, Z, rng
+
+
+@settings(max_examples=60, **COMMON)
+@given(kernel_case())
+def test_oracle_kernel_matrices_are_symmetric_psd_with_unit_diagonal(case):
+    name, var, ls, X, Z, rng = case
+    k = ok.Kernel(name, var, ls)
+    K = k.K(X)
+    # GPflow's expansion |a|^2 + |b|^2 - 2 a.b goes through a BLAS product: symmetric to rounding, not bitwise
+    assert np.max(np.abs(K - K.T)) <= 1e-12 * var
+    tol = 1e-12 if name != "matern12" else 3e-7  # matern12: sqrt of the cancelled squared distance
+    assert np.max(np.abs(np.diag(K) - var)) <= tol * var
+    assert np.linalg.eigvalsh(0.5 * (K + K.T)).min() >= -1e-9 * var * X.shape[0]
+    assert np.all(K <= var * (1 + 1e-12)) and np.all(K >= 0)
+    Kxz = k.K(X, Z)
+    assert Kxz.shape == (X.shape[0], Z.shape[0]) and np.allclose(Kxz, k.K(Z, X).T, rtol=0, atol=1e-12 * var)
+    # shard-sum invariance of the transpose product (the multi-GPU decomposition)
+    w = rng.standard_normal((X.shape[0], 2))
+    whole = Kxz.T @ w
+    G = min(4, X.shape[0])
+    per = -(-X.shape[0] // G)
+    parts = sum(k.K(X[g * per:(g + 1) * per], Z).T @ w[g * per:(g + 1) * per] for g in range(G))
+    assert np.allclose(parts, whole, rtol=1e-12, atol=1e-12 * (1 + np.abs(whole).max()))
+
+
+@settings(max_examples=30, **COMMON)
+@given(st.integers(2, 40), st.integers(1, 4), st.integers(0, 2 ** 31 - 1))
+def test_oracle_cg_meets_its_own_stopping_rule(n, nrhs, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, 2))
+    A = ok.Kernel("se", 1.0, np.ones(2)).K(X) + 0.3 * np.eye(n)
+    B = rng.standard_normal((n, nrhs))
+    sol, (steps, err) = ocg.ConjugateGradient(1e-10).solve_with_stats(A, B)
+    assert steps <= n
+    r = A @ sol - B
+    # stopped by the rule (every column under the threshold) or by the cap n
+    assert np.all(0.5 * np.sum(r * r, axis=0) <= 1e-10 * 1.01) or steps == n
+
+
+def T(a, dt=torch.float64):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device="cuda:0", dtype=dt)
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.gpu
+@settings(max_examples=120, **COMMON)
+@given(kernel_case(max_n=700, max_m=300, max_d=12), st.integers(1, 9))
+def test_gpu_fused_products_on_random_shapes(case, R):
+    from cggp import kernels, ops
+    name, var, ls, X, Z, rng = case
+    cls = {"se": kernels.SquaredExponential, "matern12": kernels.Matern12, "matern32": kernels.Matern32,
+           "matern52": kernels.Matern52}[name]
+    k, ko = cls(var, ls), ok.Kernel(name, var, ls)
+    spec = k.spec(X.shape[1])
+    K = ko.K(X, Z)
+    tol = 1e-11 if name != "matern12" else 3e-7
+    V = rng.standard_normal((Z.shape[0], R))
+    W = rng.standard_normal((X.shape[0], R))
+    assert rel(ops.knm_matvec(spec, T(X), T(Z), T(V)), K @ V) < tol
+    assert rel(ops.kmn_matvec(spec, T(X), T(Z), T(W)), K.T @ W) < tol
+    assert rel(ops.k_dense(spec, T(X), T(Z)), K) < tol
+    assert rel(ops.kmn_knm(spec, T(X), T(Z)), K.T @ K) < max(tol, 1e-11)
+    idx = ops.nearest_center(spec, T(X), T(Z), return_distance=False).cpu().numpy()
+    d2 = ok.square_distance(Z, X).T
+    chosen = d2[np.arange(X.shape[0]), idx]
+    assert np.all(chosen <= d2.min(axis=1) * (1 + 1e-12) + 1e-12)
+    y = rng.standard_normal((X.shape[0],))
+    for method in ("sweep", "sorted"):
+        sums, cnt = ops.cluster_stats(torch.from_numpy(idx).to("cuda:0"), T(y), Z.shape[0], method=method)
+        ref = np.zeros(Z.shape[0])
+        np.add.at(ref, idx, y)
+        assert np.array_equal(cnt.cpu().numpy(), np.bincount(idx, minlength=Z.shape[0]).astype(np.float64))
+        assert np.max(np.abs(sums.cpu().numpy() - ref)) <= 1e-12 * (1 + np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@settings(max_examples=80, **COMMON)
+@given(st.integers(1, 1300), st.integers(1, 140), st.integers(0, 2 ** 31 - 1), st.sampled_from([torch.float64, torch.float32]))
+def test_gpu_symmetric_product_on_random_shapes(n, Bt, seed, dt):
+    """Every regime of `p @ A` (upper-triangle GEMV, row GEMV, LDS-staged skinny, NT GEMM, k-sliced GEMM)."""
+    from cggp import ops
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    P = rng.standard_normal((Bt, n))
+    out = ops.symm_matmul(T(A, dt), T(P, dt))
+    assert out.shape == (Bt, n)
+    assert rel(out.double(), P @ A) < (1e-12 if dt == torch.float64 else 3e-4)
+
+
+@pytest.mark.gpu
+@settings(max_examples=40, **COMMON)
+@given(st.integers(2, 300), st.integers(1, 70), st.integers(0, 2 ** 31 - 1), st.integers(1, 12))
+def test_gpu_cg_fixed_steps_on_random_shapes(n, Bt, seed, k):
+    """A few steps of the device CG against the oracle for random sizes (all update-kernel variants)."""
+    from cggp.conjugate_gradient import conjugate_gradient
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, 2))
+    A = ok.Kernel("se", 1.0, np.ones(2)).K(X) + 0.5 * np.eye(n)
+    B = rng.standard_normal((Bt, n))
+    k = min(k, 6)
+    sol, (steps, err) = conjugate_gradient(T(A), T(B), None, 0.0, max_iterations=k, max_steps_cycle=k + 1,
+                                           check_every=3)
+    o_sol, (o_steps, o_err) = ocg.conjugate_gradient(A, B, np.zeros_like(B), 0.0, max_iterations=k,
+                                                     max_steps_cycle=k + 1)
+    assert int(steps) == o_steps == k
+    assert rel(sol, o_sol) < 1e-8
