@@ -221,3 +221,25 @@ def test_gpu_generic_dimension_path_on_random_shapes(D, N, M, R, name, seed):
     assert rel(ops.k_dense(spec, T(X), T(Z)), K) < tol
     assert rel(ops.knm_matvec(spec, T(X), T(Z), T(V)), K @ V) < tol
     assert rel(ops.kmn_matvec(spec, T(X), T(Z), T(W)), K.T @ W) < tol
+
+
+@settings(max_examples=_n(40), **COMMON)
+@given(st.integers(2, 160), st.integers(1, 4), st.integers(1, 5), st.booleans(), st.booleans(), st.integers(0, 2 ** 31 - 1))
+def test_host_covertree_matches_the_oracle_on_random_inputs(N, D, levels, lloyds, voronoi, seed):
+    """libmgp's host cover tree (no GPU) node for node against the numpy oracle."""
+    import warnings
+    from cggp.covertree import CoverTree
+    from oracle import covertree as oct_
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, D))
+    y = rng.standard_normal((N, 1))
+    ref = oct_.CoverTree((x, y), num_levels=levels, lloyds=lloyds, voronoi=voronoi)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = CoverTree(None, (x, y), num_levels=levels, lloyds=lloyds, voronoi=voronoi)
+    assert [len(lv) for lv in got.levels] == [len(lv) for lv in ref.levels]
+    for lg, lr in zip(got.levels, ref.levels):
+        for a, b in zip(lg, lr):
+            assert np.allclose(a.point, b.point, rtol=0, atol=1e-12) and np.array_equal(a.rows, b.rows)
+    leaves = np.sort(np.concatenate([nd.rows for nd in got.levels[-1]]))
+    assert np.array_equal(leaves, np.arange(N))
