@@ -16,7 +16,10 @@ constexpr int NT = 256;
 
 // RPT rows per thread: one LDS read of a centre feeds RPT distance chains (with one row per thread the
 // kernel was LDS-issue bound: 5 operand reads per 13 VALU instructions)
-template <typename T, int DP, int KIND, int RPT>
+// DIRECT (dist_type 1, the reference's `euclid_distance`, distance.py:9-11): the squared distance is
+// the sum of squared differences, exactly 0 for coincident points, as `norm(x - y)` gives; the other
+// types use GPflow's expansion |a|^2 + |b|^2 - 2 a.b, as `ops.square_distance` and the kernels do.
+template <typename T, int DP, int KIND, int RPT, bool DIRECT>
 __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, long N, const T* __restrict__ Z,
                                                      long M, int D, SweepParams prm, int dist_type,
                                                      long* __restrict__ idx, T* __restrict__ best) {
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, lo
       for (int d = 0; d < DP; ++d) {
         T v = (d < D && j < M) ? Z[j * D + d] * (T)prm.inv_ls[d] : (T)0;
         s = mgp_fma(v, v, s);
-        p[d] = v + v;
+        p[d] = DIRECT ? v : v + v;
       }
-      p[DP] = j < M ? s : (T)INFINITY;
+      p[DP] = j < M ? (DIRECT ? (T)0 : s) : (T)INFINITY;
     }
     __syncthreads();
     const int lim = (M - j0) < TB ? (int)(M - j0) : TB;
@@ -69,9 +72,19 @@ __global__ __launch_bounds__(NT) void nearest_kernel(const T* __restrict__ X, lo
       for (int d = 0; d <= DP; ++d) pv[d] = p[d];
 #pragma unroll
       for (int q = 0; q < RPT; ++q) {
-        T s = pv[DP] + a2[q];  // |a|^2 + |b|^2 - 2 a.b  (GPflow's expansion)
+        T s;
+        if (DIRECT) {
+          s = pv[DP];  // 0, or +inf past the last centre
 #pragma unroll
-        for (int d = 0; d < DP; ++d) s = mgp_fma(-a[q][d], pv[d], s);
+          for (int d = 0; d < DP; ++d) {
+            const T df = a[q][d] - pv[d];
+            s = mgp_fma(df, df, s);
+          }
+        } else {
+          s = pv[DP] + a2[q];  // |a|^2 + |b|^2 - 2 a.b  (GPflow's expansion)
+#pragma unroll
+          for (int d = 0; d < DP; ++d) s = mgp_fma(-a[q][d], pv[d], s);
+        }
         if (s < bs[q]) {  // strict: first index on ties while j ascends
           bs[q] = s;
           bj[q] = (int)j0 + jj;
@@ -156,9 +169,15 @@ int nearest_dp(mgp_handle* h, const SweepParams& prm, int D, int dist_type, cons
   int rpt = D <= 8 ? 4 : 2;
   while (rpt > 1 && (N + (long)NT * rpt - 1) / ((long)NT * rpt) < 2L * h->num_cus) rpt >>= 1;
   dim3 grid((unsigned)((N + (long)NT * rpt - 1) / ((long)NT * rpt)));
-#define MGP_NC1(DPV, RV)                                                                                         \
-  hipLaunchKernelGGL((nearest_kernel<T, DPV, KIND, RV>), grid, dim3(NT), 0, h->stream, X, N, Z, M, D, prm, dist_type, \
-                     idx, best)
+#define MGP_NC1(DPV, RV)                                                                                        \
+  do {                                                                                                          \
+    if (dist_type == 1)                                                                                         \
+      hipLaunchKernelGGL((nearest_kernel<T, DPV, KIND, RV, true>), grid, dim3(NT), 0, h->stream, X, N, Z, M, D, prm, \
+                         dist_type, idx, best);                                                                 \
+    else                                                                                                        \
+      hipLaunchKernelGGL((nearest_kernel<T, DPV, KIND, RV, false>), grid, dim3(NT), 0, h->stream, X, N, Z, M, D,  \
+                         prm, dist_type, idx, best);                                                            \
+  } while (0)
 #define MGP_NC(DPV)          \
   do {                       \
     if (rpt == 4) {          \

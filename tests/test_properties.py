@@ -243,3 +243,59 @@ def test_host_covertree_matches_the_oracle_on_random_inputs(N, D, levels, lloyds
             assert np.allclose(a.point, b.point, rtol=0, atol=1e-12) and np.array_equal(a.rows, b.rows)
     leaves = np.sort(np.concatenate([nd.rows for nd in got.levels[-1]]))
     assert np.array_equal(leaves, np.arange(N))
+
+
+@pytest.mark.gpu
+@settings(max_examples=_n(30), **COMMON)
+@given(kernel_case(max_n=400, max_m=40, max_d=3), st.floats(0.2, 0.95), st.integers(2, 60))
+def test_gpu_models_and_selection_on_random_problems(case, rho, cap):
+    """CDGP predict / prior KL and the selection algorithms on random problems against the oracle."""
+    from cggp import kernels, selection
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import CGGP
+    from oracle import models as om, selection as osel
+    name, var, ls, X, Z, rng = case
+    if name == "matern12":
+        name = "matern32"  # coincident-point noise of matern12 (DESIGN 2.3) would set every tolerance here
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32, "matern52": kernels.Matern52}[name]
+    k, ko = cls(var, ls), ok.Kernel(name, var, ls)
+    N, M = X.shape[0], Z.shape[0]
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    idx = oc.nearest_centre_sqdist(Z, X)
+    u, counts = oc.cluster_stats(idx, y, M)
+    u = np.where(np.isnan(u), 0.0, u)
+    cg = ConjugateGradient(1e-15, max_iterations=4000)
+    m = CGGP(k, 0.1, T(Z), cg, num_probes=None, pseudo_u=T(u), cluster_counts=T(counts))
+    ref = om.CGGP(ko, 0.1, Z, ocg.ConjugateGradient(1e-15, max_iterations=4000), num_probes=None, pseudo_u=u,
+                  cluster_counts=counts)
+    Xs = X[:min(N, 37)] + 0.03
+    mu, v = m.predict_f(T(Xs))
+    mu0, v0 = ref.predict_f(Xs)
+    assert np.max(np.abs(mu.cpu().numpy() - mu0)) < 1e-6 * (1 + np.abs(mu0).max())
+    assert np.max(np.abs(v.cpu().numpy() - v0)) < 1e-6 * var
+    kl, kl0 = m.prior_kl(), ref.prior_kl()
+    assert abs(kl - kl0) < 1e-6 * (1 + abs(kl0))
+    # selection: identical index sequences
+    Z0, i0 = osel.oips(ko, X, rho, cap)
+    Z1, i1 = selection.oips(k, T(X), rho, cap, chunk=64)
+    assert np.array_equal(i1.cpu().numpy(), i0)
+    perm = rng.permutation(N)
+    g0 = osel.greedy_selection(ko, X, min(cap, N), perm)[1]
+    g1 = selection.greedy_selection(k, T(X), min(cap, N), perm=torch.from_numpy(perm))[1]
+    # a tie in the conditional variances may be broken differently at rounding level: compare until the first
+    # disagreement and require the disagreeing picks to have equal conditional variance to 1e-9
+    same = np.nonzero(g1.cpu().numpy() != g0)[0]
+    if same.size:
+        first = int(same[0])
+        assert first >= 1
+        Kx = ko.K(X)
+        S = list(g0[:first])
+        def cond_var(j):
+            Kss = Kx[np.ix_(S, S)] + 1e-12 * np.eye(len(S))
+            return Kx[j, j] - Kx[j, S] @ np.linalg.solve(Kss, Kx[S, j])
+        assert abs(cond_var(int(g0[first])) - cond_var(int(g1[first]))) < 1e-8 * var
+    kc = min(5, N)
+    c0 = X[rng.choice(N, kc, replace=False)]
+    C0, md0 = osel.kmeans_lloyd(X, kc, 1e-7, c0)
+    C1, md1 = selection.kmeans_lloyd(T(X), kc, 1e-7, T(c0))
+    assert np.max(np.abs(C1.cpu().numpy() - C0)) < 1e-8 and abs(md1 - md0) < 1e-8
