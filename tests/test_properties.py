@@ -299,3 +299,45 @@ def test_gpu_models_and_selection_on_random_problems(case, rho, cap):
     C0, md0 = osel.kmeans_lloyd(X, kc, 1e-7, c0)
     C1, md1 = selection.kmeans_lloyd(T(X), kc, 1e-7, T(c0))
     assert np.max(np.abs(C1.cpu().numpy() - C0)) < 1e-8 and abs(md1 - md0) < 1e-8
+
+
+@pytest.mark.gpu
+@settings(max_examples=_n(12), **COMMON)
+@given(kernel_case(max_n=300, max_m=90, max_d=9))
+def test_gpu_kernel_gradient_and_sgpr_on_random_problems(case):
+    """`mgp_k_dense_vjp` against central differences of the oracle's kernel, and the SGPR model (matrix-free,
+    preconditioned, explicit-S) against the two-Cholesky closed form, on random problems."""
+    from cggp import kernels, ops
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import SGPR
+    from oracle import models as om
+    name, var, ls, X, Z, rng = case
+    if name == "matern12":
+        name = "matern32"  # not differentiable at coincident points; coincident-point noise (DESIGN 2.3)
+    N, D = X.shape
+    M = Z.shape[0]
+    G = rng.standard_normal((N, M))
+    spec = ops.KernelSpec(name, var, ls.tolist(), D)
+    dvar, dls = ops.k_dense_vjp(spec, T(X), T(Z), T(G))
+    f = lambda v, l: float(np.sum(G * ok.Kernel(name, v, l).K(X, Z)))
+    h = 1e-6
+    scale = 1.0 + np.abs(G).sum()
+    assert abs(dvar - (f(var + h, ls) - f(var - h, ls)) / (2 * h)) < 1e-8 * scale
+    d = int(rng.integers(0, D))
+    e = np.zeros(D)
+    e[d] = h
+    assert abs(dls[d] - (f(var, ls + e) - f(var, ls - e)) / (2 * h)) < 1e-7 * scale
+    # SGPR
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32, "matern52": kernels.Matern52}[name]
+    k, ko = cls(var, ls), ok.Kernel(name, var, ls)
+    y = np.cos(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((N, 1))
+    ref = om.SGPR((X, y), ko, Z, 0.15, jitter=1e-6)
+    Xs = X[:min(N, 20)] + 0.02
+    mu0, v0 = ref.predict_f(Xs)
+    for pre, explicit in ((None, 0), ("auto", 8)):
+        m = SGPR((T(X), T(y)), k, T(Z), 0.15, ConjugateGradient(1e-14, max_iterations=6000), jitter=1e-6,
+                 preconditioner=pre, explicit_rhs=explicit)
+        mu, v = m.predict_f(T(Xs))
+        assert np.max(np.abs(mu.cpu().numpy() - mu0)) < 1e-5 * (1 + np.abs(mu0).max())
+        assert np.max(np.abs(v.cpu().numpy() - v0)) < 1e-5 * var
+    assert abs(m.elbo() - ref.elbo()) < 1e-7 * abs(ref.elbo())
