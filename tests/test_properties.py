@@ -341,3 +341,57 @@ def test_gpu_kernel_gradient_and_sgpr_on_random_problems(case):
         assert np.max(np.abs(mu.cpu().numpy() - mu0)) < 1e-5 * (1 + np.abs(mu0).max())
         assert np.max(np.abs(v.cpu().numpy() - v0)) < 1e-5 * var
     assert abs(m.elbo() - ref.elbo()) < 1e-7 * abs(ref.elbo())
+
+
+@pytest.mark.gpu
+@settings(max_examples=_n(25), **COMMON)
+@given(kernel_case(max_n=400, max_m=60, max_d=4), st.integers(1, 7), st.integers(1, 64))
+def test_gpu_fp32_probes_and_batched_prediction_on_random_problems(case, P, batch):
+    """fp32 products and solves against the fp64 oracle at fp32 tolerances; the Hutchinson branches with
+    injected probes; batched prediction with and without the shared inverse."""
+    from cggp import kernels, ops
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import CGGP, eval_logdet_grad
+    from oracle import models as om
+    name, var, ls, X, Z, rng = case
+    if name == "matern12":
+        name = "matern52"
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32, "matern52": kernels.Matern52}[name]
+    k, ko = cls(var, ls), ok.Kernel(name, var, ls)
+    N, D = X.shape
+    M = Z.shape[0]
+    spec = k.spec(D)
+    K = ko.K(X, Z)
+    V, W = rng.standard_normal((M, 2)), rng.standard_normal((N, 2))
+    f32 = torch.float32
+    assert rel(ops.knm_matvec(spec, T(X, f32), T(Z, f32), T(V, f32)).double(), K @ V) < 2e-4
+    assert rel(ops.kmn_matvec(spec, T(X, f32), T(Z, f32), T(W, f32)).double(), K.T @ W) < 2e-4
+    lam = rng.uniform(0.1, 0.5, M)
+    KL = ko.K(Z) + np.diag(lam)
+    B = rng.standard_normal((M, 3))
+    sol32 = ConjugateGradient(1e-9, max_iterations=4 * M + 20)(T(KL, f32), T(B, f32))
+    assert rel(sol32.double(), np.linalg.solve(KL, B)) < 5e-3
+    # Hutchinson branches with injected probes
+    probes = rng.choice([-1.0, 1.0], size=(M, P))
+    idx = oc.nearest_centre_sqdist(Z, X)
+    y = np.sin(X.sum(1, keepdims=True))
+    u, counts = oc.cluster_stats(idx, y, M)
+    u = np.where(np.isnan(u), 0.0, u)
+    cg = ConjugateGradient(1e-15, max_iterations=4000)
+    m = CGGP(k, 0.1, T(Z), cg, num_probes=P, pseudo_u=T(u), cluster_counts=T(counts))
+    ref = om.CGGP(ko, 0.1, Z, ocg.ConjugateGradient(1e-15, max_iterations=4000), num_probes=P, pseudo_u=u,
+                  cluster_counts=counts)
+    kl, kl0 = m.prior_kl(probes=T(probes)), ref.prior_kl(probes=probes)
+    assert abs(kl - kl0) < 1e-6 * (1 + abs(kl0))
+    KLo = om.add_diagonal(ok.Kuu(Z, ko), (0.1 / counts)[:, 0])
+    G = eval_logdet_grad(T(KLo), cg, 1.0, probes=T(probes))
+    G0 = om.eval_logdet_grad(KLo, ocg.ConjugateGradient(1e-15, max_iterations=4000), 1.0, probes=probes)
+    assert rel(G, G0) < 1e-6
+    # batched prediction: per-batch CG, shared inverse, one shot
+    Xs = X + 0.01
+    mu1, v1 = m.predict_f(T(Xs))
+    mu2, v2 = m.predict_f_batched(T(Xs), batch)
+    mu3, v3 = m.predict_f_batched(T(Xs), batch, shared_inverse=True)
+    for mu, v in ((mu2, v2), (mu3, v3)):
+        assert float((mu - mu1).abs().max()) < 1e-7 * (1 + float(mu1.abs().max()))
+        assert float((v - v1).abs().max()) < 1e-6 * var
