@@ -395,3 +395,34 @@ def test_gpu_fp32_probes_and_batched_prediction_on_random_problems(case, P, batc
     for mu, v in ((mu2, v2), (mu3, v3)):
         assert float((mu - mu1).abs().max()) < 1e-7 * (1 + float(mu1.abs().max()))
         assert float((v - v1).abs().max()) < 1e-6 * var
+
+
+@pytest.mark.gpu
+@settings(max_examples=_n(30), **COMMON)
+@given(st.integers(1, 500), st.integers(1, 200), st.integers(1, 10), st.sampled_from(KINDS),
+       st.sampled_from([1e-3, 1e-2, 30.0, 1e3]), st.sampled_from([1.0, 50.0, 400.0]), st.integers(0, 2 ** 31 - 1))
+def test_gpu_fused_products_at_extreme_scales(N, M, D, name, ls_scale, x_scale, seed):
+    """Tiny lengthscales / huge coordinates (exponents far outside the table path's range: the clamped
+    loop, underflow to exact zeros) and huge lengthscales (every k ~ variance)."""
+    from cggp import kernels, ops
+    rng = np.random.default_rng(seed)
+    ls = rng.uniform(0.5, 2.0, D) * ls_scale
+    X = rng.standard_normal((N, D)) * x_scale
+    Z = np.concatenate([X[: min(N, M // 2 + 1)], rng.standard_normal((M, D)) * x_scale])[:M]  # some coincident points
+    cls = {"se": kernels.SquaredExponential, "matern12": kernels.Matern12, "matern32": kernels.Matern32,
+           "matern52": kernels.Matern52}[name]
+    k, ko = cls(0.7, ls), ok.Kernel(name, 0.7, ls)
+    K = ko.K(X, Z)
+    spec = k.spec(D)
+    V = rng.standard_normal((Z.shape[0], 2))
+    W = rng.standard_normal((N, 2))
+    # absolute tolerance on the scale of the variance: GPflow's expansion cancels |a|^2 + |b|^2 - 2 a.b, so the
+    # error of the *scaled* squared distance is eps * (|a|^2 + |b|^2) / l^2 -- both sides carry it
+    r2max = 2.0 * float(np.max(np.sum((X / ls) ** 2, axis=1)) + np.max(np.sum((Z / ls) ** 2, axis=1)))
+    tol = max(1e-11, 4e-16 * r2max) * (10.0 if name != "matern12" else 3e4)
+    Kd = ops.k_dense(spec, T(X), T(Z)).cpu().numpy()
+    assert np.all(np.isfinite(Kd)) and np.max(np.abs(Kd - K)) <= tol * 0.7
+    u = ops.knm_matvec(spec, T(X), T(Z), T(V)).cpu().numpy()
+    t = ops.kmn_matvec(spec, T(X), T(Z), T(W)).cpu().numpy()
+    assert np.max(np.abs(u - K @ V)) <= tol * 0.7 * (1 + np.abs(V).sum(0).max())
+    assert np.max(np.abs(t - K.T @ W)) <= tol * 0.7 * (1 + np.abs(W).sum(0).max())
