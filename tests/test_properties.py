@@ -426,3 +426,51 @@ def test_gpu_fused_products_at_extreme_scales(N, M, D, name, ls_scale, x_scale, 
     t = ops.kmn_matvec(spec, T(X), T(Z), T(W)).cpu().numpy()
     assert np.max(np.abs(u - K @ V)) <= tol * 0.7 * (1 + np.abs(V).sum(0).max())
     assert np.max(np.abs(t - K.T @ W)) <= tol * 0.7 * (1 + np.abs(W).sum(0).max())
+
+
+@pytest.mark.gpu
+@settings(max_examples=_n(8), **COMMON)
+@given(st.integers(20, 150), st.integers(3, 16), st.integers(1, 3), st.sampled_from(["se", "matern32", "matern52"]),
+       st.integers(0, 2 ** 31 - 1))
+def test_gpu_elbo_gradient_on_random_problems(N, M, D, name, seed):
+    """Gradient of the differentiable ELBO (exact branch) through the device CG -- including the
+    proportional-dx shortcut and the reused probe solve -- against central differences of the oracle's
+    Cholesky twin, whose ELBO differs by the omitted 0.5 log|Kmm+Lambda| only in value, not in gradient."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import TrainableCGGP
+    from oracle import models as om
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-2, 2, (N, D))
+    y = np.sin(X.sum(1, keepdims=True)) + 0.2 * rng.standard_normal((N, 1))
+    Z = X[rng.choice(N, M, replace=False)] + 0.05 * rng.standard_normal((M, D))
+    idx = oc.nearest_centre_sqdist(Z, X)
+    u, counts = oc.cluster_stats(idx, y, M)
+    u = np.where(np.isnan(u), 0.0, u)
+    var, ls, s2 = float(rng.uniform(0.5, 2.0)), rng.uniform(0.6, 1.8, D), float(rng.uniform(0.05, 0.4))
+    cls = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32, "matern52": kernels.Matern52}[name]
+    m = TrainableCGGP(cls(var, ls), s2, T(Z), ConjugateGradient(1e-15, max_iterations=6000), num_probes=None,
+                      pseudo_u=T(u), cluster_counts=T(counts), num_data=N)
+    B = min(N, 40)
+    e = m.elbo((T(X[:B]), T(y[:B])))
+    e.backward()
+    sig = lambda p: torch.sigmoid(p.raw.detach())
+    g_var = float(m.kernel.variance_p.raw.grad / sig(m.kernel.variance_p))
+    g_ls = (m.kernel.lengthscales_p.raw.grad / sig(m.kernel.lengthscales_p)).numpy().reshape(-1)
+    g_s2 = float(m.noise_p.raw.grad / sig(m.noise_p))
+
+    def twin(v, l, s):
+        t = om.ClusterGP(ok.Kernel(name, v, l), s, Z, pseudo_u=u, cluster_counts=counts, num_data=N)
+        return float(t.elbo((X[:B], y[:B])))
+
+    h = 1e-5
+    fd_var = (twin(var + h, ls, s2) - twin(var - h, ls, s2)) / (2 * h)
+    fd_s2 = (twin(var, ls, s2 + h) - twin(var, ls, s2 - h)) / (2 * h)
+    scale = max(1.0, abs(fd_var), abs(fd_s2))
+    assert abs(g_var - fd_var) < 2e-4 * scale, (g_var, fd_var)
+    assert abs(g_s2 - fd_s2) < 2e-4 * scale, (g_s2, fd_s2)
+    d = int(rng.integers(0, D))
+    dl = np.zeros(D)
+    dl[d] = h
+    fd = (twin(var, ls + dl, s2) - twin(var, ls - dl, s2)) / (2 * h)
+    assert abs(g_ls[d] - fd) < 2e-4 * max(scale, abs(fd)), (d, g_ls[d], fd)
