@@ -36,3 +36,27 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert d["convergence_preconditioned"]["converged"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 launch of the contract (torch.distributed.run, one rank per process) rehearsed with gloo
+    on the one GPU of the box: row sharding, the all-reduce hook, max-over-ranks timing, rank 0 prints."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--rows", "65536",
+                          "--convergence-cap", "8", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 32768 and d["scaling"] == "strong"
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert d["convergence_preconditioned"]["converged"] is True
+    assert d["cdgp_same_size"]["cg_iterations"] > 0
