@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    ap.add_argument("--cpu-sample-rows", type=int, default=393216)  # ~13 s of host work on 16 cores
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--convergence-cap", type=int, default=0, help="iteration cap of the convergence leg (0 = M)")
     ap.add_argument("--force-collective", action="store_true",
