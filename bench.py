@@ -32,12 +32,16 @@ import torch.distributed as dist  # noqa: E402
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet (== fp64 matrix peak); MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
-# What csrc/sweep.hip executes per pair on the SE fast path: distance D fma; exp2 by table with
-# |a|^2 folded into the magic constant: 3 add, 2 fma, mul, fma, ldexp (8 fp64 instr, 11 flop) + and/ashr/lshl;
-# RC accumulate fma
-EXEC_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
-EXEC_VALU_INSTR_PER_PAIR = lambda D, R: D + 8 + 3 + R
-NUM_SIMDS, MAX_CLOCK_HZ, FP64_CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
+# ALGORITHMIC flops per pair of the fused SE product, frozen at round 1's count so that rounds
+# compare: distance D fma (2D) + exp2 on a reduced argument (3 add, 2 fma, mul, fma, scale = 11) + R accumulate fma
+# (2R).  The kernel may execute fewer instructions than this (round 2 does); time is what is measured.
+ALG_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
+# VALU wave-instructions the current kernels issue per pair, by element size (csrc/sweep_fast.hip fp64 SE:
+# D + 3 + 3 + R fp64 and 3 integer; csrc/sweep.hip fp32 SE: D fma + v_exp_f32 + R fma), and the cycles one
+# wave-instruction holds a SIMD (fp64 16 lanes/clk -> 4; fp32 and 32-bit integer 32 lanes/clk -> 2)
+VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 6 + R, 3), 4: lambda D, R: (D + 1 + R, 0)}  # (float, int32)
+NUM_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
+CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (2, 2)}  # (float, int32) by element size
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
 
 
@@ -154,13 +158,14 @@ def main():
                  "p90_ms": float(np.percentile(durs, 90))} if durs.size else None
     R = 1
     pairs_launch = float(n_local) * M
-    flops_launch = pairs_launch * EXEC_FLOPS_PER_PAIR(D, R)
-    issue_s = (pairs_launch / 64.0) * EXEC_VALU_INSTR_PER_PAIR(D, R) * FP64_CYCLES_PER_WAVE_INSTR / (
-        NUM_SIMDS * MAX_CLOCK_HZ)
+    flops_launch = pairs_launch * ALG_FLOPS_PER_PAIR(D, R)
+    n_fl, n_int = VALU_INSTR_PER_PAIR[esize](D, R)
+    c_fl, c_int = CYCLES_PER_WAVE_INSTR[esize]
+    issue_s = (pairs_launch / 64.0) * (n_fl * c_fl + n_int * c_int) / (NUM_SIMDS * MAX_CLOCK_HZ)
     bytes_launch = float(esize) * (n_local * D + M * D + M * R + n_local * R)
     ach_tflops = flops_launch / (sweep_ms * 1e-3) / 1e12
     vector_peak = FP64_VECTOR_PEAK_TFLOPS if esize == 8 else FP32_VECTOR_PEAK_TFLOPS
-    flop_model_exact = esize == 8 and kname == "se"
+    flop_model_exact = kname == "se"
     ach_gbps = bytes_launch / (sweep_ms * 1e-3) / 1e9
     equiv_gemv_gbps = float(esize) * n_local * M / (sweep_ms * 1e-3) / 1e9
 
@@ -221,6 +226,8 @@ def main():
                "half_rz_final": float(err.max().item()),
                "true_half_residual_sq": 0.5 * float((rres * rres).sum().item())}
     except Exception as e:
+        if world > 1:
+            raise  # the leg contains collectives: a rank must not drop out of them silently
         pcg = {"error": repr(e)}
 
     # ---- CDGP leg at the same size (informational; SURVEY §8e: no per-iteration collective):
@@ -238,6 +245,7 @@ def main():
             torch.cuda.synchronize()
             return r, 1e3 * (time.perf_counter() - t)
 
+        (_, _, _), t_assign_first = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
         (_, sums, counts), t_assign = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
         counts = torch.where(counts != 0, counts, torch.ones_like(counts))
         u = (sums / counts)[:, None]
@@ -256,11 +264,13 @@ def main():
         (_, t_ldg) = timed(lambda: mdl.logdet_gradient(1.0, probes=probes))
         cdgp_probe = {"prior_kl_64_probes_ms": t_kl, "prior_kl": kl, "logdet_gradient_64_probes_ms": t_ldg,
                       "probe_cg_iterations": int(cgm.last_stats[0])}
-        cdgp = {"assign_and_stats_ms": t_assign, "kuu_lambda_ms": t_k, "cg_iterations": int(csteps),
+        cdgp = {"assign_and_stats_ms": t_assign, "assign_and_stats_first_call_ms": t_assign_first, "kuu_lambda_ms": t_k, "cg_iterations": int(csteps),
                 "cg_ms": t_cg, "cg_half_rz_final": float(cerr.max().item()),
                 "true_half_residual_sq": 0.5 * float((res * res).sum().item()),
                 "predict_mean_all_local_rows_ms": t_mean, **cdgp_probe}
     except Exception as e:  # the headline number must not depend on this leg
+        if world > 1:
+            raise  # collectives inside: see above
         cdgp = {"error": repr(e)}
 
     cpu = None
@@ -294,18 +304,19 @@ def main():
                        "N": N, "D": D, "M": M, "rhs": 1, "rows_per_gpu": n_local,
                        "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M] per step"},
             "roofline": {
-                "bound": "mfma",
-                "bound_note": "fp64 compute roofline: on MI355X the fp64 vector and matrix peaks are the same 78.6 "
-                              "TFLOP/s and share the ALUs; this kernel issues VALU (DESIGN.md 4.1), it is not HBM-bound "
-                              "(SURVEY 8d) -- the hbm figures BASELINE.json asks for are in the nested object",
+                "bound": "valu",
+                "bound_note": "vector-ALU issue roofline: the kernel issues no MFMA (DESIGN.md 4.1: on MI355X the fp64 "
+                              "matrix and vector peaks are the same 78.6 TFLOP/s on the same ALUs, measured and "
+                              "rejected) and is not HBM-bound (SURVEY 8d) -- the hbm figures BASELINE.json asks for "
+                              "are in the nested object",
                 "kernel": f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1> (K_nm.p and K_mn.u are the "
                           "same symbol)",
                 "achieved": ach_tflops, "peak": vector_peak, "unit": "TFLOP/s",
                 "frac": ach_tflops / vector_peak,
-                "flop_model": "counted from the fp64 SE fast path of csrc/sweep.hip" if flop_model_exact else
-                              "the fp64 SE instruction count applied to another dtype/kernel: approximate",
-                "flop_per_pair": EXEC_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
-                "valu_instr_per_pair": EXEC_VALU_INSTR_PER_PAIR(D, R),
+                "flop_model": "algorithmic flops of the fused SE product, DESIGN.md 4.1 (2D + 11 + 2R per pair)"
+                              if flop_model_exact else "the SE count applied to another kernel: approximate",
+                "flop_per_pair": ALG_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
+                "valu_instr_per_pair": {"float": n_fl, "int32": n_int},
                 "valu_issue_frac_at_2.4GHz": issue_s / (sweep_ms * 1e-3),
                 "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
                 "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
@@ -318,6 +329,16 @@ def main():
                         "equiv_dense_gemv_GBps_derived": equiv_gemv_gbps},
             },
             "cpu_baseline": cpu,
+            # "converging to residual <= 1e-6" (north star): the reference recurrence (identity preconditioner)
+            # and the preconditioned one, each with iterations and wall time to the reference's stopping rule
+            "iterations_to_threshold": {
+                "reference_recurrence": (conv["iterations"] if conv and conv["converged"] else None),
+                "preconditioned": (pcg.get("iterations") if pcg and pcg.get("converged") else None)},
+            "time_to_solution_s": {
+                "reference_recurrence": (conv["seconds"] if conv and conv["converged"] else None),
+                "preconditioned": ((pcg["build_seconds"] + pcg["solve_seconds"])
+                                   if pcg and pcg.get("converged") else None),
+                "note": "None = the iteration cap (the reference's default n = M) was hit before 0.5||r||^2 <= 1e-6"},
             "convergence": conv,
             "convergence_preconditioned": pcg,
             "cdgp_same_size": cdgp,

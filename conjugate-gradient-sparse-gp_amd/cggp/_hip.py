@@ -11,8 +11,10 @@ import threading
 
 import torch
 
+MGP_VERSION = 200
 MGP_MAX_D = 512
 MGP_FUSED_MAX_D = 32
+MGP_COMM_ID_BYTES = 128
 F32, F64 = 0, 1
 SE, MATERN12, MATERN32, MATERN52 = 0, 1, 2, 3
 COLS, ROWS = 0, 1
@@ -60,6 +62,9 @@ class MgpOperator(ctypes.Structure):
         ("partial_buf", ctypes.c_void_p),
         ("kmm_row_begin", ctypes.c_int64),
         ("kmm_row_end", ctypes.c_int64),
+        ("comm", ctypes.c_void_p),
+        ("world_size", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -86,6 +91,8 @@ _KP = ctypes.POINTER(MgpKernel)
 SIGNATURES = {
     "mgp_version": (_I, []),
     "mgp_create": (_I, [ctypes.POINTER(_P), _I]),
+    "mgp_create_ex": (_I, [ctypes.POINTER(_P), _I, ctypes.c_size_t]),
+    "mgp_workspace_bytes": (ctypes.c_size_t, [_P]),
     "mgp_destroy": (_I, [_P]),
     "mgp_set_stream": (_I, [_P, _P]),
     "mgp_last_error": (ctypes.c_char_p, [_P]),
@@ -109,6 +116,17 @@ SIGNATURES = {
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),
     "mgp_profile_read_each": (_I, [_P, ctypes.POINTER(_D), _L, ctypes.POINTER(_L)]),
+    # collectives: RCCL communicator ranks
+    "mgp_comm_unique_id": (_I, [_P]),
+    "mgp_comm_init_rank": (_I, [ctypes.POINTER(_P), _I, _I, _I, _P]),
+    "mgp_comm_init_all": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_P)]),
+    "mgp_comm_destroy": (_I, [_P]),
+    "mgp_comm_size": (_I, [_P]),
+    "mgp_comm_rank": (_I, [_P]),
+    "mgp_comm_group_begin": (_I, []),
+    "mgp_comm_group_end": (_I, []),
+    "mgp_allreduce_sum": (_I, [_P, ctypes.c_size_t, _I, _P, _P]),
+    "mgp_comm_last_error": (ctypes.c_char_p, []),
     # host-only entry points (cover tree, row F3)
     "mgp_host_last_error": (ctypes.c_char_p, []),
     "mgp_covertree_build": (_I, [_P, _L, _I, _D, _I, _I, _I, ctypes.POINTER(_P)]),
@@ -160,9 +178,10 @@ class Handle:
         self.lib = load_library()
         self.device_index = device_index
         h = ctypes.c_void_p()
-        rc = self.lib.mgp_create(ctypes.byref(h), device_index)
+        ws = int(os.environ.get("MGP_WORKSPACE_BYTES", "0") or 0)  # > 0: fixed workspace, no hipMalloc after create
+        rc = self.lib.mgp_create_ex(ctypes.byref(h), device_index, ws)
         if rc != 0:
-            raise MgpError(f"mgp_create(device={device_index}) failed with {rc}")
+            raise MgpError(f"mgp_create_ex(device={device_index}, workspace_bytes={ws}) failed with {rc}")
         self.h = h
 
     def check(self, rc):

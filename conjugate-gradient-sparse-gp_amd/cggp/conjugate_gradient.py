@@ -149,17 +149,34 @@ class SgprNormalOperator(LinearOperator):
         self.kmm_rows = kmm_rows if allreduce is not None else None
         self._partial = None
         self._cb = None
-        if allreduce is not None:
-            self._ensure_partial(max_rhs)
+        self.reserve(max_rhs)
+
+    @property
+    def _comm(self):
+        """libmgp RCCL communicator when the exchange is native (parallel.AllReduce on backend nccl)."""
+        return getattr(self.allreduce, "comm", None)
+
+    def _world(self):
+        w = getattr(self.allreduce, "world_size", None)
+        if w is None:
+            import torch.distributed as dist
+            w = dist.get_world_size() if dist.is_initialized() else 1
+        return int(w)
 
     def _ensure_partial(self, Bt):
-        if self._partial is None or self._partial.shape[0] < Bt:
-            self._partial = torch.empty((Bt, self.shape[0]), dtype=self.dtype, device=self.device)
+        # hook path only (gloo rehearsal): the collective addresses this buffer as a torch tensor.
+        # Bt*M partial + 1 agreement word (csrc/cg.hip: every rank must have taken part in a step)
+        need = Bt * self.shape[0] + 1
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty((need,), dtype=self.dtype, device=self.device)
             buf = self._partial
 
             def _cb(ctx, ptr_, count, dtype_c, stream):
                 try:
-                    self.allreduce(buf.view(-1)[:count])
+                    # libmgp enqueued the partial on `stream` (its handle's stream == torch's current one,
+                    # _hip.get_handle); make that explicit for the collective
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=buf.device)):
+                        self.allreduce(buf[:count])
                     return 0
                 except Exception:  # never let an exception cross the C boundary
                     import traceback
@@ -169,7 +186,7 @@ class SgprNormalOperator(LinearOperator):
             self._cb = _hip.ALLREDUCE_FN(_cb)
 
     def reserve(self, Bt):
-        if self.allreduce is not None:
+        if self.allreduce is not None and self._comm is None:
             self._ensure_partial(Bt)
 
     def _struct(self):
@@ -185,15 +202,22 @@ class SgprNormalOperator(LinearOperator):
         st.M = self.shape[0]
         st.Kmm = self.Kmm.data_ptr()
         st.s2 = self.s2
+        keep = (k, self.X, self.Z, self.Kmm)
         if self.allreduce is not None:
-            st.allreduce = self._cb
-            st.partial_buf = self._partial.data_ptr()
+            if self._comm is not None:  # native RCCL: no callback, no staging buffer
+                st.comm = self._comm.ptr
+                keep += (self._comm,)
+            else:
+                st.allreduce = self._cb
+                st.partial_buf = self._partial.data_ptr()
+                st.world_size = self._world()
+                keep += (self._partial, self._cb)
             if self.kmm_rows is not None:
                 st.kmm_row_begin, st.kmm_row_end = int(self.kmm_rows[0]), int(self.kmm_rows[1])
             else:  # no slab given: rank 0 alone adds the replicated term
                 import torch.distributed as dist
                 st.kmm_row_begin, st.kmm_row_end = (0, self.shape[0]) if dist.get_rank() == 0 else (0, -1)
-        return st, (k, self.X, self.Z, self.Kmm, self._partial, self._cb)
+        return st, keep
 
     def rmatmul(self, P):
         self.reserve(P.shape[0])
@@ -429,11 +453,15 @@ def _solve_device(op, rhs, initial_solution, error_threshold, preconditioner, ma
 class _CGFunction(torch.autograd.Function):
     """Custom gradient of reference :100-118: db = CG(A, dx) from zero, dA = -solution^T @ db.
 
-    Shortcut (exact): when every row of the incoming `dx` is a multiple of the same row of the
-    forward right-hand side -- `dx_b = c_b rhs_b`, which is what a loss that touches the solution
-    only through `sum(rhs * solution)` sends back (the predictive-variance term `sum(Kmn * W)` of
-    the ELBO, `cggp/models.py:343`) -- then `CG(A, dx)_b = c_b solution_b` and the second solve is
-    skipped.  `conjugate_gradient.backward_shortcuts` counts how often that happened."""
+    Shortcut: when every row of the incoming `dx` is a multiple of the same row of the forward
+    right-hand side -- `dx_b = c_b rhs_b`, which is what a loss that touches the solution only through
+    `sum(rhs * solution)` sends back (the predictive-variance term `sum(Kmn * W)` of the ELBO,
+    `cggp/models.py:343`) -- then `c_b solution_b` solves `db A = dx` with residual `c_b r_b`, i.e.
+    `0.5||r||^2 = c_b^2 err_b`.  It is returned as it stands only when that already meets the reference's
+    absolute rule `<= error_threshold` for every row (the second solve would then stop at step 0 or
+    land within the same tolerance); otherwise it is the INITIAL SOLUTION of the second solve, which
+    then needs a few steps instead of a full solve.  `conjugate_gradient.backward_shortcuts` counts the
+    first case, `backward_warm_starts` the second."""
 
     @staticmethod
     def forward(ctx, matrix, rhs, initial_solution, cfg):
@@ -442,26 +470,35 @@ class _CGFunction(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.matrix = matrix
         ctx.zero_start = initial_solution is None
-        ctx.save_for_backward(sol, rhs)
+        ctx.save_for_backward(sol, rhs, err)
         ctx.mark_non_differentiable(err)
         ctx.stats = stats
         return sol, err
 
     @staticmethod
     def backward(ctx, dx, _derr):
-        sol, rhs = ctx.saved_tensors
+        sol, rhs, err = ctx.saved_tensors
         op = as_operator(ctx.matrix)
         dx = dx.contiguous()
         db = None
+        warm = None
         if ctx.zero_start:
             rr = (rhs * rhs).sum(dim=1, keepdim=True)
             c = (dx * rhs).sum(dim=1, keepdim=True) / torch.where(rr > 0, rr, torch.ones_like(rr))
             tol = 1e-12 if dx.dtype == torch.float64 else 1e-5
             if bool(((dx - c * rhs).abs().max() <= tol * dx.abs().max()).item()):
-                db = c * sol
-                conjugate_gradient.backward_shortcuts += 1
+                # err = 0.5 rz of the forward solve (= 0.5||r||^2 for the identity preconditioner; for
+                # others recompute the true residual of c*sol below through the warm start)
+                thr = float(ctx.cfg[0])
+                plain = ctx.cfg[1] is None or isinstance(ctx.cfg[1], EyePreconditioner)
+                if plain and bool(((c * c) * err <= thr).all().item()):
+                    db = c * sol
+                    conjugate_gradient.backward_shortcuts += 1
+                else:
+                    warm = (c * sol).contiguous()
+                    conjugate_gradient.backward_warm_starts += 1
         if db is None:
-            db, _, _ = _solve_device(op, dx, None, *ctx.cfg)
+            db, _, _ = _solve_device(op, dx, warm, *ctx.cfg)
         dA = None
         if isinstance(ctx.matrix, torch.Tensor) and ctx.needs_input_grad[0]:
             dA = -(sol.t() @ db)  # [n,Bt]x[Bt,n] library GEMM (rank-Bt update)
@@ -491,6 +528,7 @@ def conjugate_gradient(matrix, rhs, initial_solution, error_threshold, precondit
 
 conjugate_gradient.last_stats = None
 conjugate_gradient.backward_shortcuts = 0
+conjugate_gradient.backward_warm_starts = 0
 
 
 class ConjugateGradient:

@@ -375,8 +375,8 @@ class SGPR:
     def __init__(self, data, kernel, inducing_variable, noise_variance, conjugate_gradient=None, *,
                  jitter=1e-6, allreduce=None, num_data=None, preconditioner="auto", explicit_rhs=8,
                  kmm_solver="cholesky"):
-        """`preconditioner`: "auto" (the subsampled normal-equation preconditioner when this
-        rank holds at least 32 rows per inducing point, else none), None, or a
+        """`preconditioner`: "auto" (the subsampled normal-equation preconditioner when the data
+        set -- all ranks together -- holds at least 32 rows per inducing point, else none), None, or a
         `CGPreconditioner` for the [M,M] system.  `explicit_rhs`: solves on S with at least this
         many right-hand sides form S once on the matrix cores (`ops.kmn_knm`, 2NM^2 flops) and run
         the dense CG on it -- a matrix-free step costs two N x M sweeps per right-hand-side chunk,
@@ -392,20 +392,51 @@ class SGPR:
         self.conjugate_gradient = conjugate_gradient or ConjugateGradient(1e-6)
         self.jitter = float(jitter)
         self.allreduce = allreduce
-        self.num_data = num_data if num_data is not None else self.X.shape[0]
+        if num_data is None:
+            # rows of X may be this rank's shard: N of the bound and of the "auto" preconditioner rule
+            # is the GLOBAL row count, agreed by one all-reduce (every rank must call the constructor)
+            num_data = self.X.shape[0]
+            if allreduce is not None:
+                t = torch.tensor([float(num_data)], dtype=torch.float64, device=self.X.device)
+                allreduce(t)
+                num_data = int(round(t.item()))
+        self.num_data = num_data
         self.preconditioner = preconditioner
         self.explicit_rhs = int(explicit_rhs)
         if kmm_solver not in ("cholesky", "cg"):
             raise ValueError(f"unknown kmm_solver {kmm_solver!r}")
         self.kmm_solver = kmm_solver
+        self.invalidate()
+
+    # ---- caches.  Everything below is a function of (X, Y, Z, kernel and likelihood parameters,
+    # jitter); `update_fn` / `multiple_assign` / `assign_inducing_parameters` change those from
+    # outside (cggp/cli_utils.py:394-411, paper_cli_uci.py:123-124), so every public method first
+    # compares a fingerprint of them and drops the caches when it moved.
+    def invalidate(self):
         self._Lmm = None
         self._alpha = None
         self._op = None
         self._cg_S = None
         self._S = None
         self._KK = None
+        self._key = self._fingerprint()
+        # keep the fingerprinted tensors alive: id() of a freed tensor can be handed to the next one
+        self._key_refs = (self.inducing_variable.Z, self.X, self.Y)
+
+    def _fingerprint(self):
+        Z = self.inducing_variable.Z
+        k = self.kernel
+        return (id(Z), Z._version, tuple(Z.shape), id(self.X), self.X._version, id(self.Y), self.Y._version,
+                type(k).__name__, float(k.variance), tuple(float(v) for v in k.lengthscales),
+                float(self.likelihood.variance), float(self.jitter), id(self.conjugate_gradient),
+                id(self.preconditioner) if not isinstance(self.preconditioner, str) else self.preconditioner)
+
+    def _sync(self):
+        if self._fingerprint() != self._key:
+            self.invalidate()
 
     def operator(self):
+        self._sync()
         if self._op is None:
             self._op = SgprNormalOperator(self.kernel, self.X, self.inducing_variable.Z,
                                           self.likelihood.variance, jitter=self.jitter,
@@ -414,13 +445,16 @@ class SGPR:
 
     def solver(self):
         """The CG used on S: the model's `conjugate_gradient` settings plus the preconditioner."""
+        self._sync()
         if self._cg_S is None:
             cg, pre = self.conjugate_gradient, self.preconditioner
             if isinstance(pre, str):
                 if pre != "auto":
                     raise ValueError(f"unknown preconditioner {pre!r}")
                 M = self.inducing_variable.Z.shape[0]
-                pre = SubsampledNormalPreconditioner(self.operator()) if self.X.shape[0] >= 32 * M else None
+                # decided on the global N: the preconditioner's build contains collectives, so every
+                # rank must take the same branch whatever its own shard holds
+                pre = SubsampledNormalPreconditioner(self.operator()) if self.num_data >= 32 * M else None
             if pre is None:
                 self._cg_S = cg
             else:
@@ -435,12 +469,14 @@ class SGPR:
 
     def dense_S(self):
         """S = s2 (Kmm + jitter I) + K_mn K_nm as an [M,M] matrix (formed once, cached)."""
+        self._sync()
         if self._S is None:
             self._S = torch.add(self.kmn_knm(), self.operator().Kmm, alpha=self.likelihood.variance)
         return self._S
 
     def kmn_knm(self):
         """K_mn K_nm [M,M] on the matrix cores, summed over ranks (formed once, cached)."""
+        self._sync()
         if self._KK is None:
             Z = self.inducing_variable.Z
             KK = ops.kmn_knm(self.kernel.spec(Z.shape[1]), self.X, Z)
@@ -451,6 +487,7 @@ class SGPR:
 
     def solve_S(self, rhs):
         """S^-1 rhs for rhs [M, R]: matrix-free for a few columns, explicit S beyond `explicit_rhs`."""
+        self._sync()
         if self._S is not None or (self.explicit_rhs > 0 and rhs.shape[1] >= self.explicit_rhs):
             return self.solver()(self.dense_S(), rhs)
         return self.solver()(self.operator(), rhs)
@@ -463,12 +500,14 @@ class SGPR:
         return b
 
     def alpha(self):
+        self._sync()
         if self._alpha is None:
             self._alpha = self.solve_S(self._Kmn_y())
         return self._alpha
 
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
         assert not full_output_cov
+        self._sync()
         iv, kernel = self.inducing_variable, self.kernel
         mean = ops.knm_matvec(kernel.spec(Xnew.shape[1]), Xnew, iv.Z, self.alpha())
         Kms = Kuf(iv, kernel, Xnew)
@@ -487,6 +526,7 @@ class SGPR:
 
     def elbo(self):
         """Titsias' collapsed bound, GPflow `SGPR.elbo` (const + logdet + quad + trace)."""
+        self._sync()
         iv, kernel = self.inducing_variable, self.kernel
         Z = iv.Z
         s2 = self.likelihood.variance

@@ -6,7 +6,12 @@ M-sized CG state are replicated, so every rank runs the identical CG recurrence 
 exchange is one all-reduce(sum) of the [Bt, M] partial product per operator application.
 """
 
+import ctypes
+
+import torch
 import torch.distributed as dist
+
+from . import _hip
 
 
 def shard_bounds(N, world_size, rank):
@@ -26,27 +31,84 @@ def shard_rows(t, world_size=None, rank=None):
     return t[lo:hi]
 
 
-def make_allreduce(group=None, force=False):
-    """In-place sum over ranks of a flat tensor view; None when there is a single rank.
+class Communicator:
+    """One RCCL rank owned by libmgp (`mgp_comm`, include/mgp.h).  torch.distributed is used only to
+    ship the 128-byte unique id from rank 0 to the others; every collective of the data path is then
+    `mgp_allreduce_sum` (ncclAllReduce) on torch's current stream, or -- inside `mgp_pcg_solve` --
+    issued by the library itself on the solve's stream with no Python in the step."""
 
-    The tensor is a view of a buffer the caller owns (libmgp hands the partial product to the
-    collective through `SgprNormalOperator`'s buffer), the call is enqueued behind the kernels
-    already on torch's current stream.
-    """
-    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-        return None
+    def __init__(self, group=None, device=None):
+        lib = _hip.load_library()
+        self.lib = lib
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        box = [None]
+        if rank == 0:
+            buf = (ctypes.c_char * _hip.MGP_COMM_ID_BYTES)()
+            rc = lib.mgp_comm_unique_id(buf)
+            if rc != 0:
+                raise _hip.MgpError(f"mgp_comm_unique_id failed ({rc}): {lib.mgp_comm_last_error().decode()}")
+            box[0] = bytes(buf.raw)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        c = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(box[0], _hip.MGP_COMM_ID_BYTES)
+        rc = lib.mgp_comm_init_rank(ctypes.byref(c), device.index, world, rank, idbuf)
+        if rc != 0:
+            raise _hip.MgpError(f"mgp_comm_init_rank failed ({rc}): {lib.mgp_comm_last_error().decode()}")
+        self.ptr, self.world_size, self.rank, self.device = c, world, rank, device
 
-    host_staged = dist.get_backend(group) == "gloo"
+    def allreduce(self, t):
+        """In-place sum of a contiguous CUDA tensor (view) over the ranks, on torch's current stream."""
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("Communicator.allreduce needs a contiguous CUDA tensor")
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        rc = self.lib.mgp_allreduce_sum(ctypes.c_void_p(t.data_ptr()), t.numel(), _hip.dtype_code(t), self.ptr,
+                                        ctypes.c_void_p(stream))
+        if rc != 0:
+            raise _hip.MgpError(f"mgp_allreduce_sum failed ({rc}): {self.lib.mgp_comm_last_error().decode()}")
 
-    def _allreduce(t):
-        if host_staged and t.is_cuda:  # gloo rehearsal of the N > 1 path on a single-GPU box
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.mgp_comm_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AllReduce:
+    """In-place sum over ranks of a flat tensor view.  `comm` is set when the exchange is native RCCL
+    (backend "nccl"): `SgprNormalOperator` then hands the communicator to libmgp and the per-step
+    all-reduce never leaves the library.  Otherwise (gloo: rehearsal of the N > 1 path on CPU-staged
+    buffers) the call goes through torch.distributed and libmgp reaches it by its callback hook."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.host_staged = dist.get_backend(group) == "gloo"
+        self.comm = None if self.host_staged else Communicator(group)
+
+    def __call__(self, t):
+        if self.comm is not None:
+            self.comm.allreduce(t)
+        elif t.is_cuda:  # gloo: stage through the host
             c = t.cpu()
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(c)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    return _allreduce
+
+def make_allreduce(group=None, force=False):
+    """`AllReduce` for the current process group; None when there is a single rank (unless `force`,
+    which runs the collective on a 1-rank group to measure its fixed per-step cost)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return None
+    return AllReduce(group)
 
 
 def kmm_slab(M, world_size=None, rank=None):

@@ -57,13 +57,37 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   return MGP_OK;
 }
 
+extern "C" int mgp_create_ex(mgp_handle** out, int device, size_t workspace_bytes) {
+  MGP_TRY(mgp_create(out, device));
+  if (workspace_bytes == 0) return MGP_OK;
+  mgp_handle* h = *out;
+  if (hipMalloc(&h->pool, workspace_bytes) != hipSuccess) {
+    (void)mgp_destroy(h);
+    *out = nullptr;
+    return MGP_E_NOMEM;
+  }
+  h->pool_bytes = workspace_bytes;
+  return MGP_OK;
+}
+
+extern "C" size_t mgp_workspace_bytes(const mgp_handle* h) {
+  if (!h) return 0;
+  if (h->pool) return h->pool_used;
+  // 256 bytes of alignment slack per arena, as a fixed pool would spend
+  return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + 4 * 256;
+}
+
 extern "C" int mgp_destroy(mgp_handle* h) {
   if (!h) return MGP_OK;
   (void)hipSetDevice(h->device);
-  if (h->ws) (void)hipFree(h->ws);
-  if (h->cg) (void)hipFree(h->cg);
-  if (h->opws) (void)hipFree(h->opws);
-  if (h->gen) (void)hipFree(h->gen);
+  if (h->pool) {
+    (void)hipFree(h->pool);  // the arenas live inside it
+  } else {
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->cg) (void)hipFree(h->cg);
+    if (h->opws) (void)hipFree(h->opws);
+    if (h->gen) (void)hipFree(h->gen);
+  }
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);

@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict
   s_rz = block_sum(s_rz, red);
   s_rr = block_sum(s_rr, red);
   const T beta = (mode == 2 || mode == 5 || rz_old <= min_float) ? (T)0 : s_rz / rz_old;
-  for (long j = threadIdx.x; j < n; j += blockDim.x) p[off + j] = mgp_fma(beta, p[off + j], zz[j]);
+  // p = z where the beta-term is dropped (:79-84): a select, not 0 * p -- at start-up (mode 5) p is
+  // whatever the arena held, and 0 * Inf/NaN would poison the direction
+  const bool drop = mode == 2 || mode == 5 || rz_old <= min_float;
+  for (long j = threadIdx.x; j < n; j += blockDim.x) p[off + j] = drop ? zz[j] : mgp_fma(beta, p[off + j], zz[j]);
   if (threadIdx.x == 0) {
     rz[blockIdx.x] = s_rz;
     err[blockIdx.x] = (T)0.5 * s_rz;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
     const long j = (long)e * NT + t;
     if (j < n) {
       r[off + j] = rv[e];
-      p[off + j] = mgp_fma(beta, pv[e], zv[e]);
+      p[off + j] = (rz_old <= min_float) ? zv[e] : mgp_fma(beta, pv[e], zv[e]);
     }
   }
   if (t == 0) {
@@ -323,7 +326,31 @@ __global__ __launch_bounds__(256) void add_diag_prod_kernel(const int* __restric
   if (i < total) out[i] = mgp_fma(lam[i % n], p[i], out[i]);
 }
 
+// Multi-rank agreement: the word behind the [Bt,M] partial carries this rank's gate
+// (1 = it computed this application) through the all-reduce; the sum equals the number of ranks
+// iff every rank did.
+template <typename T>
+__global__ void put_gate_word_kernel(const int* __restrict__ gate, T* __restrict__ word) {
+  *word = (gate == nullptr || *gate != 0) ? (T)1 : (T)0;
+}
+
+// After the all-reduce: out = reduced partial when every rank took part; otherwise nobody uses this
+// application and the local gate closes, so all ranks leave the CG loop on the same iteration.
+template <typename T>
+__global__ __launch_bounds__(256) void finish_allreduce_kernel(int* __restrict__ gate, const T* __restrict__ tt,
+                                                               T* __restrict__ out, long tot, int world) {
+  const int a = gate == nullptr ? 1 : *gate;
+  if (!a) return;
+  if (tt[tot] != (T)world) {  // exact: a sum of at most `world` ones
+    if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *gate = 0;
+    return;
+  }
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < tot) out[i] = tt[i];
+}
+
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
 
 // out[Bt, n] = P[Bt, n] @ Op ; gate may be null
 template <typename T>
@@ -344,12 +371,13 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       // u[Bt,N] = (K_nm p^T)^T ; t[Bt,M] = (K_mn u^T)^T over the local rows ; the replicated
       // s2*Kmm.p term is added as this rank's row slab of it, so ONE all-reduce of t finishes S.p
       const long N = op->N, M = op->M;
-      // operator arena: u [Bt,N] | partial [Bt,M] | Kmm.p [Bt,M] (only for Bt > 1)
-      const size_t need = ((size_t)Bt * N + 2 * (size_t)Bt * M) * sizeof(T);
+      const bool coll = op->allreduce != nullptr || op->comm != nullptr;
+      // operator arena: u [Bt,N] | partial [Bt,M] + agreement word (padded to 2) | Kmm.p [Bt,M] (only for Bt > 1)
+      const size_t need = ((size_t)Bt * N + 2 * (size_t)Bt * M + 2) * sizeof(T);
       MGP_TRY(mgp_reserve(h, &h->opws, &h->opws_bytes, need));
       T* u = (T*)h->opws;
       // the collective works on the caller's buffer when one is given; single rank: straight into out
-      T* tt = op->allreduce ? (op->partial_buf ? (T*)op->partial_buf : u + Bt * N) : out;
+      T* tt = coll ? (op->partial_buf ? (T*)op->partial_buf : u + Bt * N) : out;
       if (N > 0) {
         MGP_TRY(mgp_sweep(h, op->kernel, op->X, N, op->Z, M, VecView{P, 1, M}, (int)Bt, VecViewMut{u, 1, N}, 0.0,
                           VecView{nullptr, 0, 0}, gate));
@@ -364,16 +392,26 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
         MGP_TRY(mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, op->s2, tt, gate));
       } else {
         // several RHS: full replicated product, then only this rank's slab of it is added
-        T* kmp = u + Bt * N + Bt * M;
+        T* kmp = u + Bt * N + Bt * M + 2;
         MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, op->Kmm, M, P, Bt, kmp, gate));
         hipLaunchKernelGGL((add_rows_slab_kernel<T>), dim3(nblk(Bt * M)), dim3(256), 0, h->stream, gate, (T)op->s2,
                            (const T*)kmp, tt, M, Bt * M, rb, re);
         MGP_LAUNCH_CHECK(h);
       }
-      if (op->allreduce) {
-        const int rc = op->allreduce(op->allreduce_ctx, tt, (size_t)(Bt * M), op->dtype, (void*)h->stream);
-        if (rc != 0) return mgp_fail(h, MGP_E_COMM, "allreduce callback returned %d", rc);
-        MGP_HIP(h, hipMemcpyAsync(out, tt, (size_t)Bt * M * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+      if (coll) {
+        const long tot = Bt * M;
+        hipLaunchKernelGGL((put_gate_word_kernel<T>), dim3(1), dim3(1), 0, h->stream, gate, tt + tot);
+        MGP_LAUNCH_CHECK(h);
+        if (op->allreduce) {  // rehearsal hook (gloo with host staging); never used with RCCL
+          const int rc = op->allreduce(op->allreduce_ctx, tt, (size_t)(tot + 1), op->dtype, (void*)h->stream);
+          if (rc != 0) return mgp_fail(h, MGP_E_COMM, "allreduce callback returned %d", rc);
+        } else {  // native: one ncclAllReduce on the solve's stream
+          MGP_TRY(mgp_comm_allreduce_on(h, op->comm, tt, (size_t)(tot + 1), op->dtype));
+        }
+        const int world = op->comm ? mgp_comm_size(op->comm) : op->world_size;
+        hipLaunchKernelGGL((finish_allreduce_kernel<T>), dim3(nblk(tot)), dim3(256), 0, h->stream, (int*)gate,
+                           (const T*)tt, out, tot, world);
+        MGP_LAUNCH_CHECK(h);
       }
       return MGP_OK;
     }
@@ -395,6 +433,10 @@ int check_operator(mgp_handle* h, const mgp_operator* op) {
     if (op->kind == MGP_OP_SGPR && (!op->Kmm || op->N < 0 || (op->N > 0 && !op->X)))
       return mgp_fail(h, MGP_E_BADARG, "SGPR operator needs X and Kmm");
     if (op->kind == MGP_OP_KMM_LAMBDA && !op->lambda) return mgp_fail(h, MGP_E_BADARG, "needs lambda");
+    if (op->kind == MGP_OP_SGPR && op->allreduce && op->comm)
+      return mgp_fail(h, MGP_E_BADARG, "give either the allreduce hook or a communicator, not both");
+    if (op->kind == MGP_OP_SGPR && op->allreduce && op->world_size < 1)
+      return mgp_fail(h, MGP_E_BADARG, "allreduce hook needs world_size >= 1");
   } else {
     return mgp_fail(h, MGP_E_BADARG, "unknown operator kind %d", op->kind);
   }

@@ -28,6 +28,9 @@ struct mgp_handle {
   // generic-D scratch (transposed multipliers, kernel panel, chunk output)
   void* gen = nullptr;
   size_t gen_bytes = 0;
+  // mgp_create_ex: one caller-sized block that serves every arena above; no hipMalloc/hipFree after create
+  void* pool = nullptr;
+  size_t pool_bytes = 0, pool_used = 0;
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
@@ -95,9 +98,22 @@ inline int mgp_fail(mgp_handle* h, int code, const char* fmt, ...) {
 
 #define MGP_LAUNCH_CHECK(h) MGP_HIP((h), hipGetLastError())
 
-// grow-only arenas; never called during stream capture (callers size up front)
+// grow-only arenas; never called during stream capture (callers size up front).  With a fixed
+// workspace (mgp_create_ex) an arena that must grow takes a fresh region of the pool (its old one is
+// not reused) and the request fails when the pool is exhausted -- the library never allocates then.
 inline int mgp_reserve(mgp_handle* h, void** p, size_t* have, size_t need) {
   if (need <= *have) return MGP_OK;
+  if (h->pool) {
+    const size_t at = (h->pool_used + 255) & ~(size_t)255;
+    if (at + need > h->pool_bytes)
+      return mgp_fail(h, MGP_E_NOMEM, "fixed workspace exhausted: %zu bytes requested, %zu of %zu in use "
+                      "(size it with mgp_workspace_bytes on a growing handle)", need, h->pool_used, h->pool_bytes);
+    if (*p) MGP_HIP(h, hipStreamSynchronize(h->stream));  // the old region may still be read by queued work
+    *p = (char*)h->pool + at;
+    *have = need;
+    h->pool_used = at + need;
+    return MGP_OK;
+  }
   if (*p) {
     MGP_HIP(h, hipStreamSynchronize(h->stream));
     MGP_HIP(h, hipFree(*p));
@@ -183,5 +199,7 @@ int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64
 int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale);
 int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
                            double alpha, void* out, const int* gate);
+// comm.hip: the operator's all-reduce on the handle's stream (errors land in the handle)
+int mgp_comm_allreduce_on(mgp_handle* h, mgp_comm* comm, void* buf, size_t count, int dtype);
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,
                           void* out, const int* gate);

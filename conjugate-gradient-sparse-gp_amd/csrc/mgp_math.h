@@ -55,7 +55,9 @@ MGP_HD double mgp_exp2_tab_entry(int i) { return mgp_exp2((double)i * (1.0 / MGP
 // 2(max|a|^2 + max|b|^2) per tile and fall back to the clamped loop otherwise).
 template <bool CLAMP = true>
 MGP_HD double mgp_exp2_tab(double t, const double* tab) {
-  if (CLAMP) t = __builtin_fmax(t, -2000.0);  // keeps m inside int32 for absurdly distant points; 2^-2000 == 0
+  // keeps m inside int32 for absurdly distant points (2^-2000 == 0); a comparison, not fmax, so that a
+  // NaN distance stays NaN as tf.exp would leave it (fmax(NaN, x) == x)
+  if (CLAMP) t = t < -2000.0 ? -2000.0 : t;
   const double C = 0x1.8p+41;
   const double u = t + C;
   long long bits;
@@ -161,7 +163,7 @@ MGP_HD T mgp_profile(T neg_s, T clamp, E2 e2 = E2()) {
     return e2(neg_s);
   } else {
     T s = -neg_s;
-    s = s > clamp ? s : clamp;
+    s = s < clamp ? clamp : s;  // tf.maximum(r2, 1e-36) keeps NaN: so does this form (s > clamp ? s : clamp would not)
     const T q = mgp_sqrt_pos(s);
     const T e = e2(-q);
     if (KIND == 1) return e;

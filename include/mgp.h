@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 100 /* 0.1.0 */
+#define MGP_VERSION 200 /* 0.2.0: mgp_comm, mgp_operator.comm, mgp_create_ex */
 #define MGP_MAX_D 512      /* input dimensions the library accepts (capacity of mgp_kernel) */
 #define MGP_FUSED_MAX_D 32 /* up to here the fused register-resident sweeps run; above, products go through
                             * row-chunked explicit kernel panels + the NT GEMM (the reference's dense form);
@@ -56,6 +56,8 @@ enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2, MGP_PRE_DENSE = 3
 enum { MGP_OP_DENSE = 0, MGP_OP_SGPR = 1, MGP_OP_KMM_LAMBDA = 2 };
 
 typedef struct mgp_handle mgp_handle;
+/* one RCCL communicator rank (wraps ncclComm_t); see "collectives" below */
+typedef struct mgp_comm mgp_comm;
 
 /* Kernel hyper-parameters (host memory).  lengthscales has D entries (ARD; repeat the
  * value for an isotropic kernel).  Replaces gpflow.kernels.* parameter objects. */
@@ -68,9 +70,10 @@ typedef struct {
   double lengthscales[MGP_MAX_D];
 } mgp_kernel;
 
-/* Optional collective hook: sum `count` elements of `buf` (device) in place over all ranks,
- * enqueued on `stream`.  NULL = single rank.  Used only for the [M,R] partial product of the
- * row-sharded SGPR operator -- one call per operator application. */
+/* Optional collective hook (rehearsal of the N > 1 path without RCCL, e.g. gloo with host staging):
+ * sum `count` elements of `buf` (device) in place over all ranks, enqueued on `stream`.  Used only
+ * for the [Bt*M + 1] partial product of the row-sharded SGPR operator -- one call per
+ * operator application.  The native path is `mgp_operator.comm` (RCCL, no callback). */
 typedef int (*mgp_allreduce_fn)(void* ctx, void* buf, size_t count, int dtype, void* stream);
 
 /* Linear operator handed to mgp_pcg_solve (the `matrix` argument of
@@ -91,13 +94,23 @@ typedef struct {
   /* MGP_OP_KMM_LAMBDA: (k(Z,Z) + diag(lambda)) applied matrix-free; lambda [M] device */
   const void* lambda;
   mgp_allreduce_fn allreduce; void* allreduce_ctx;
-  /* MGP_OP_SGPR, optional: caller-owned [Bt_max, M] device buffer that receives the local partial
-   * K_mn(K_nm p) before the collective (so a host-side collective can address it as its own
-   * tensor); NULL = library scratch. */
+  /* MGP_OP_SGPR with the `allreduce` hook, optional: caller-owned device buffer of Bt_max*M + 1
+   * elements that receives the local partial K_mn(K_nm p) and the agreement word (below) before
+   * the collective, so a host-side collective can address it as its own tensor; NULL = library
+   * scratch. */
   void* partial_buf;
   /* MGP_OP_SGPR, multi-rank: rows [kmm_row_begin, kmm_row_end) of Kmm whose s2*Kmm.p contribution
    * THIS rank adds to its partial (the slabs of all ranks must tile [0,M)); 0,0 = all rows. */
   int64_t kmm_row_begin, kmm_row_end;
+  /* MGP_OP_SGPR, multi-rank, native: RCCL communicator of this rank.  With `allreduce == NULL` and
+   * `comm != NULL` every operator application issues ONE ncclAllReduce(sum) of Bt*M + 1 elements on
+   * the handle's stream -- the [Bt,M] partial plus one agreement word: inside mgp_pcg_solve each
+   * rank contributes its `active` flag there, and an iteration is carried out only if the sum says
+   * every rank is active, so all ranks leave the loop on the same iteration by construction. */
+  mgp_comm* comm;
+  /* number of ranks the `allreduce` hook sums over (the agreement word is compared with it);
+   * ignored with `comm`, which knows its own size */
+  int32_t world_size; int32_t reserved;
 } mgp_operator;
 
 typedef struct {
@@ -119,6 +132,14 @@ typedef struct {
 /* ---- handle ------------------------------------------------------------------------- */
 int mgp_version(void);
 int mgp_create(mgp_handle** out, int device);
+/* As mgp_create, with the device workspace fixed up front: one allocation of `workspace_bytes`
+ * serves every internal arena (sweep partials, CG state, operator scratch) and the library never
+ * calls hipMalloc/hipFree afterwards -- a request that does not fit fails with MGP_E_NOMEM
+ * (mgp_last_error names the shortfall).  workspace_bytes == 0 behaves as mgp_create (arenas grow
+ * on demand).  mgp_workspace_bytes reports what a handle holds now: run the workload once on a
+ * growing handle, read it, and create the production handle with that figure. */
+int mgp_create_ex(mgp_handle** out, int device, size_t workspace_bytes);
+size_t mgp_workspace_bytes(const mgp_handle* h);
 int mgp_destroy(mgp_handle* h);
 int mgp_set_stream(mgp_handle* h, void* hip_stream);
 const char* mgp_last_error(mgp_handle* h);
@@ -179,6 +200,27 @@ int mgp_colwise_dot(mgp_handle* h, int dtype, const void* A, const void* B, int6
                     int64_t cols, void* out);
 /* *out = sum(A*B) over count elements (host double); Hutchinson trace, models.py:313 */
 int mgp_dot_all(mgp_handle* h, int dtype, const void* A, const void* B, int64_t count, double* out);
+
+/* ---- collectives: RCCL over xGMI, one communicator rank per GPU ----------------
+ * The reference has no collective; these are the build's own multi-GPU boundary.
+ * Two ways to form the communicator:
+ *  - one process per GPU (torch.distributed.run): rank 0 calls mgp_comm_unique_id, ships the
+ *    MGP_COMM_ID_BYTES to the other ranks by any channel, every rank calls mgp_comm_init_rank;
+ *  - one process driving ndev devices: mgp_comm_init_all(ndev, devs, comms) (ncclCommInitAll).
+ * mgp_allreduce_sum: in-place sum of `count` elements of `buf` (device) over the ranks, enqueued on
+ * `stream`; calls for several communicators of one process must be bracketed by
+ * mgp_comm_group_begin/end.  Errors: negative code, text via mgp_comm_last_error (thread local). */
+#define MGP_COMM_ID_BYTES 128
+int mgp_comm_unique_id(void* id_out);
+int mgp_comm_init_rank(mgp_comm** out, int device, int nranks, int rank, const void* id);
+int mgp_comm_init_all(int ndev, const int* devs, mgp_comm** comms);
+int mgp_comm_destroy(mgp_comm* c);
+int mgp_comm_size(const mgp_comm* c);
+int mgp_comm_rank(const mgp_comm* c);
+int mgp_comm_group_begin(void);
+int mgp_comm_group_end(void);
+int mgp_allreduce_sum(void* buf, size_t count, int dtype, mgp_comm* comm, void* stream);
+const char* mgp_comm_last_error(void);
 
 /* ---- next row F1: nearest-centre assignment + cluster statistics (optimize.py:41-98) ----
  * idx[i] = argmin_m d(Z_m, X_i) (first index on ties), dist type 0 = squared euclidean on raw

@@ -24,7 +24,7 @@ def lib():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mgp.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:int|int64_t|double|void|const char\*)\s+(mgp_\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:int|int64_t|size_t|double|void|const char\*)\s+(mgp_\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
@@ -40,13 +40,86 @@ def test_header_symbols_exported_and_typed(lib):
 
 def test_version_arch_and_struct_layout(lib):
     from cggp import _hip
-    assert lib.mgp_version() == 100
+    assert lib.mgp_version() == _hip.MGP_VERSION == 200
     assert lib.mgp_build_arch() == b"gfx950"
     # struct sizes the C side compiles to (LP64): keeps the ctypes mirror honest
     assert ctypes.sizeof(_hip.MgpKernel) == 4 * 4 + 8 + 8 * _hip.MGP_MAX_D
-    assert ctypes.sizeof(_hip.MgpOperator) == 8 + 8 + 8 * 14
+    assert ctypes.sizeof(_hip.MgpOperator) == 8 + 8 + 8 * 14 + 8 + 8
     assert ctypes.sizeof(_hip.MgpPrecond) == 8 + 8 + 8 * 4
     assert ctypes.sizeof(_hip.MgpCgStats) == 16
+
+
+_ABI_PROBE = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "mgp.h"
+#define F(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+  printf("version %d\n", mgp_version());           /* resolved from libmgp.so at link time */
+  printf("macro_version %d\n", MGP_VERSION);
+  printf("max_d %d\n", MGP_MAX_D);
+  printf("comm_id_bytes %d\n", MGP_COMM_ID_BYTES);
+  printf("sizeof.mgp_kernel %zu\n", sizeof(mgp_kernel));
+  printf("sizeof.mgp_operator %zu\n", sizeof(mgp_operator));
+  printf("sizeof.mgp_precond %zu\n", sizeof(mgp_precond));
+  printf("sizeof.mgp_cg_stats %zu\n", sizeof(mgp_cg_stats));
+  F(mgp_kernel, kind); F(mgp_kernel, dtype); F(mgp_kernel, D); F(mgp_kernel, reserved); F(mgp_kernel, variance);
+  F(mgp_kernel, lengthscales);
+  F(mgp_operator, kind); F(mgp_operator, dtype); F(mgp_operator, n); F(mgp_operator, A); F(mgp_operator, kernel);
+  F(mgp_operator, X); F(mgp_operator, N); F(mgp_operator, Z); F(mgp_operator, M); F(mgp_operator, Kmm);
+  F(mgp_operator, s2); F(mgp_operator, lambda); F(mgp_operator, allreduce); F(mgp_operator, allreduce_ctx);
+  F(mgp_operator, partial_buf); F(mgp_operator, kmm_row_begin); F(mgp_operator, kmm_row_end); F(mgp_operator, comm);
+  F(mgp_operator, world_size); F(mgp_operator, reserved);
+  F(mgp_precond, kind); F(mgp_precond, block_size); F(mgp_precond, num_blocks); F(mgp_precond, diag_inv);
+  F(mgp_precond, block_index); F(mgp_precond, block_inv); F(mgp_precond, dense_inv);
+  F(mgp_cg_stats, iterations); F(mgp_cg_stats, converged); F(mgp_cg_stats, seconds);
+  return 0;
+}
+"""
+
+
+def test_header_compiles_as_c_and_matches_the_ctypes_mirror(lib, tmp_path):
+    """A C compiler owns the ABI: include/mgp.h is compiled as plain C (gcc, -Wall -Werror -pedantic),
+    linked against libmgp.so, and every struct size and field offset it reports is compared with the
+    ctypes structures of cggp/_hip.py (the binding the tests and the product go through)."""
+    import shutil
+    import subprocess
+    from cggp import _hip
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_probe.c"
+    src.write_text(_ABI_PROBE)
+    exe = tmp_path / "abi_probe"
+    libdir = os.path.dirname(_hip.lib_path())
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+           str(exe), "-L", libdir, "-l:libmgp.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,--allow-shlib-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = dict(line.rsplit(" ", 1) for line in out.stdout.strip().splitlines())
+    got = {k: int(v) for k, v in got.items()}
+    assert got["version"] == got["macro_version"] == _hip.MGP_VERSION
+    assert got["max_d"] == _hip.MGP_MAX_D and got["comm_id_bytes"] == _hip.MGP_COMM_ID_BYTES
+    mirror = {"mgp_kernel": _hip.MgpKernel, "mgp_operator": _hip.MgpOperator, "mgp_precond": _hip.MgpPrecond,
+              "mgp_cg_stats": _hip.MgpCgStats}
+    rename = {"lambda": "lam"}  # `lambda` is a Python keyword
+    checked = 0
+    for key, val in got.items():
+        if key.startswith("sizeof."):
+            assert ctypes.sizeof(mirror[key[7:]]) == val, key
+            checked += 1
+        elif "." in key:
+            st, field = key.split(".")
+            assert getattr(mirror[st], rename.get(field, field)).offset == val, key
+            checked += 1
+    assert checked == 4 + 6 + 20 + 7 + 3
+    # and the other direction: the mirror declares no field the header does not have
+    for st, cls in mirror.items():
+        for fname, _ in cls._fields_:
+            back = {v: k for k, v in rename.items()}.get(fname, fname)
+            assert f"{st}.{back}" in got, (st, fname)
 
 
 def test_null_handle_is_an_error_not_a_crash(lib):

@@ -123,10 +123,24 @@ def _gpu_worker(rank, world, port, out):
     from cggp.conjugate_gradient import SubsampledNormalPreconditioner
     pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=3)
     psol, (psteps, _) = ConjugateGradient(1e-12, preconditioner=pre, max_iterations=3000).solve_with_stats(op, rhs)
+    # the SGPR model on an UNEVEN split that straddles the "auto" preconditioner rule (32 rows per inducing
+    # point): 2000 rows in all (>= 32 * 40 = 1280), 1300 on rank 0 and 700 on rank 1.  N of the bound and the
+    # preconditioner decision must come from the global row count on every rank, or the ranks take different
+    # branches around collectives
+    from cggp.models import SGPR
+    Xu, Zu, yu, _ = _problem(N=2000, D=3, M=40)
+    cut = (0, 1300) if rank == 0 else (1300, 2000)
+    Xr, yr = (torch.from_numpy(a[cut[0]:cut[1]].copy()).to(dev) for a in (Xu, yu))
+    m = SGPR((Xr, yr), kern, torch.from_numpy(Zu).to(dev), 0.1, ConjugateGradient(1e-12, max_iterations=3000),
+             jitter=1e-6, allreduce=parallel.make_allreduce())
+    assert m.num_data == 2000
+    uses_pre = m.solver().preconditioner.__class__.__name__
+    elbo = m.elbo()
+    mu, var = m.predict_f(torch.from_numpy(Xu[:50].copy()).to(dev))
     torch.cuda.synchronize()
     if rank == 0:
         out.put((Sv.cpu().numpy(), sol.cpu().numpy(), int(steps), psol.cpu().numpy(), int(psteps),
-                 pre.sample_rows))
+                 pre.sample_rows, uses_pre, elbo, mu.cpu().numpy(), var.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -140,7 +154,7 @@ def test_two_rank_sgpr_cg_on_one_gpu():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    Sv, sol, steps, psol, psteps, sample_rows = q.get()
+    Sv, sol, steps, psol, psteps, sample_rows, uses_pre, elbo, mu, var = q.get()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
@@ -156,3 +170,11 @@ def test_two_rank_sgpr_cg_on_one_gpu():
     assert np.max(np.abs(sol - exact)) / scale < 1e-6 and np.max(np.abs(o_sol - exact)) / scale < 1e-6
     assert sample_rows == 2 * (32 * 40 // 2) and psteps < steps
     assert np.max(np.abs(psol - exact)) / scale < 1e-6
+    # uneven shards: same decision on both ranks, bound and predictions of the whole data set
+    assert uses_pre == "SubsampledNormalPreconditioner"
+    Xu, Zu, yu, _ = _problem(N=2000, D=3, M=40)
+    ref = om.SGPR((Xu, yu), ok.Kernel("matern32", 1.2, [0.8, 1.0, 1.3]), Zu, 0.1, jitter=1e-6)
+    assert abs(elbo - ref.elbo()) / abs(ref.elbo()) < 1e-9
+    rmu, rvar = ref.predict_f(Xu[:50])
+    assert np.max(np.abs(mu - rmu)) / np.max(np.abs(rmu)) < 1e-6
+    assert np.max(np.abs(var - rvar)) / np.max(np.abs(rvar)) < 1e-4

@@ -29,7 +29,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] in ("hbm", "mfma", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["hbm"]["bound"] == "hbm" and r["launches_timed"] == 6
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):

@@ -623,25 +623,57 @@ def test_cg_custom_gradient():
 
 
 def test_cg_custom_gradient_proportional_shortcut():
-    """loss = sum(rhs * CG(A, rhs)): the incoming dx equals rhs, so db = solution without a second
-    solve; gradients equal the closed form d/dB = 2 A^-1 B, d/dA = -(A^-1 B)(A^-1 B)^T."""
+    """loss = c * sum(rhs * CG(A, rhs)): the incoming dx is c * rhs, so c * solution solves the backward
+    system with residual c * r.  It is returned as is only while c^2 * err still meets the reference's
+    absolute rule (conjugate_gradient.py:59-62); for a large scale (the ELBO's num_data/batch factor) it
+    becomes the warm start of the second solve.  Gradients equal the closed form
+    d/dB = 2c A^-1 B, d/dA = -c (A^-1 B)(A^-1 B)^T either way."""
     from cggp.conjugate_gradient import conjugate_gradient
     A, rhs = cg_problem(n=40, noise=0.1)
-    At = T(A).requires_grad_(True)
-    bt = T(rhs.T).requires_grad_(True)
-    before = conjugate_gradient.backward_shortcuts
-    sol, _ = conjugate_gradient(At, bt, None, 1e-15, max_iterations=400)
-    (3.0 * (sol * bt.detach()).sum()).backward()
-    assert conjugate_gradient.backward_shortcuts == before + 1
     X = np.linalg.solve(A, rhs)
-    assert relerr(bt.grad, 3.0 * X.T) < 1e-6
-    assert relerr(At.grad, -3.0 * X @ X.T) < 1e-6
-    # a loss that is not of that form takes the second solve
-    At.grad = None
+    for c, thr in ((1.0, 1e-15), (3.0, 1e-10), (1e4, 1e-10)):
+        At = T(A).requires_grad_(True)
+        bt = T(rhs.T).requires_grad_(True)
+        b0, w0 = conjugate_gradient.backward_shortcuts, conjugate_gradient.backward_warm_starts
+        sol, (_, err) = conjugate_gradient(At, bt, None, thr, max_iterations=400)
+        (c * (sol * bt.detach()).sum()).backward()
+        took_short = conjugate_gradient.backward_shortcuts - b0
+        took_warm = conjugate_gradient.backward_warm_starts - w0
+        assert took_short + took_warm == 1
+        # the rule itself: shortcut iff c^2 * err_b <= thr for every row
+        assert bool(took_short) == bool((c * c * err <= thr).all().item())
+        if c >= 1e4:
+            assert took_warm == 1  # 1e8 * err cannot meet 1e-10: the reference would have re-solved
+        assert relerr(bt.grad, c * X.T) < 1e-6
+        assert relerr(At.grad, -c * X @ X.T) < 1e-6
+    # a loss that is not of that form takes the full second solve
+    At = T(A).requires_grad_(True)
+    b0, w0 = conjugate_gradient.backward_shortcuts, conjugate_gradient.backward_warm_starts
     sol, _ = conjugate_gradient(At, T(rhs.T), None, 1e-15, max_iterations=400)
     (sol ** 2).sum().backward()
-    assert conjugate_gradient.backward_shortcuts == before + 1
+    assert (conjugate_gradient.backward_shortcuts, conjugate_gradient.backward_warm_starts) == (b0, w0)
     assert relerr(At.grad, -2.0 * X @ np.linalg.solve(A, X).T) < 1e-6
+
+
+def test_nan_inputs_propagate():
+    """GPflow's tf.exp / tf.maximum keep a NaN distance NaN (the reference's check_numerics relies on a
+    non-finite ELBO to stop a diverged run, optimize.py:359-360): a NaN row of X gives NaN in K and in
+    the fused products, for every kernel, and does not leak into other rows."""
+    from cggp import kernels, ops
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((300, 3))
+    Z = rng.standard_normal((20, 3))
+    X[7, 1] = np.nan
+    v = rng.standard_normal((20, 2))
+    for cls in (kernels.SquaredExponential, kernels.Matern12, kernels.Matern32, kernels.Matern52):
+        for dt in (torch.float64, torch.float32):
+            k = cls(1.3, [0.7, 1.0, 1.4])
+            K = k.K(T(X, dt), T(Z, dt))
+            assert torch.isnan(K[7]).all() and torch.isfinite(K[:7]).all() and torch.isfinite(K[8:]).all()
+            u = ops.knm_matvec(k.spec(3), T(X, dt), T(Z, dt), T(v, dt))
+            assert torch.isnan(u[7]).all() and torch.isfinite(u[:7]).all() and torch.isfinite(u[8:]).all()
+            t = ops.kmn_matvec(k.spec(3), T(X, dt), T(Z, dt), T(rng.standard_normal((300, 1)), dt))
+            assert torch.isnan(t).all()  # every column sum contains the NaN row
 
 
 def test_eval_logdet():
@@ -964,3 +996,71 @@ def test_lpsvgp_base_class():
     assert abs(e - e0) / abs(e0) < 1e-9
     d = LpSVGP(k, 0.2, T(Z))  # defaults: nu = 0, diag_variance = 1e-4 (:93-94)
     assert float(d.nu.abs().max()) == 0.0 and float((d.diag_variance - 1e-4).abs().max()) == 0.0
+
+
+def test_cg_start_up_ignores_stale_arena_contents():
+    """The CG state arena is reused between solves: a dense-preconditioned solve must not read what an
+    earlier solve (here: one on a NaN matrix, in the other dtype) left in it.  Found by
+    tests/test_gpu_configs.py: p = 0 * stale + z turned stale Inf/NaN bit patterns into NaN."""
+    from cggp.conjugate_gradient import DensePreconditioner, conjugate_gradient
+    rng = np.random.default_rng(31)
+    n = 96
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    b = rng.standard_normal((3, n))
+    Pinv = np.linalg.inv(A + np.diag(rng.uniform(0, 1, n)))
+    Pinv = 0.5 * (Pinv + Pinv.T)
+    bad = torch.full((n, n), float("nan"), dtype=torch.float64, device=dev())
+    conjugate_gradient(bad, torch.from_numpy(b).to(dev()), None, 1e-12, max_iterations=3)  # poisons r, p, Ap
+    A32, b32 = torch.from_numpy(A.astype(np.float32)).to(dev()), torch.from_numpy(b.astype(np.float32)).to(dev())
+    pre = DensePreconditioner(torch.from_numpy(Pinv.astype(np.float32)).to(dev()))
+    sol, (k, err) = conjugate_gradient(A32, b32, None, 1e-10, pre, max_iterations=20, max_steps_cycle=4)
+    assert torch.isfinite(sol).all() and int(k) >= 2
+    ref = np.linalg.solve(A, b.T).T
+    assert np.max(np.abs(sol.cpu().numpy() - ref)) / np.max(np.abs(ref)) < 1e-4
+
+
+def test_sgpr_caches_follow_parameter_updates():
+    """`update_fn` / `multiple_assign` / `assign_inducing_parameters` change Z and the hyper-parameters
+    from outside the model (cggp/cli_utils.py:394-411, paper_cli_uci.py:123-124): predictions and the
+    bound afterwards must be those of a freshly built SGPR, not a mix of new Z and cached alpha / Kmm /
+    K_mn K_nm."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import SGPR
+    from cggp.optimize import assign_inducing_parameters
+    from cggp.utils import multiple_assign
+    rng = np.random.default_rng(17)
+    N, D, M = 700, 2, 24
+    X, y = rng.standard_normal((N, D)), rng.standard_normal((N, 1))
+    Z0, Z1 = X[:M].copy(), X[M:2 * M + 5].copy()  # the update also changes M
+    Xs = T(X[::7])
+
+    def fresh(Z, var, ls, s2):
+        return SGPR((T(X), T(y)), kernels.Matern32(var, ls), T(Z), s2, ConjugateGradient(1e-14, max_iterations=4000),
+                    jitter=1e-6)
+
+    m = fresh(Z0, 1.0, [1.0, 1.0], 0.1)
+    mu0, var0 = m.predict_f(Xs)
+    e0 = m.elbo()
+    # 1. new inducing points (and a new M) through the reference's update path
+    assign_inducing_parameters(m, T(Z1), None, None)
+    ref = fresh(Z1, 1.0, [1.0, 1.0], 0.1)
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = ref.predict_f(Xs)
+    assert relerr(mu, rmu.cpu().numpy()) < 1e-9 and relerr(var, rvar.cpu().numpy()) < 1e-9
+    assert abs(m.elbo() - ref.elbo()) < 1e-9 * abs(ref.elbo())
+    assert relerr(mu, mu0.cpu().numpy()) > 1e-6  # and they did change
+    # 2. new hyper-parameters in place
+    multiple_assign(m, {".kernel.variance": 1.7, ".kernel.lengthscales": np.array([0.6, 1.4]),
+                        ".likelihood.variance": 0.05})
+    ref = fresh(Z1, 1.7, [0.6, 1.4], 0.05)
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = ref.predict_f(Xs)
+    assert relerr(mu, rmu.cpu().numpy()) < 1e-9 and relerr(var, rvar.cpu().numpy()) < 1e-9
+    assert abs(m.elbo() - ref.elbo()) < 1e-9 * abs(ref.elbo())
+    # 3. Z edited in place (same tensor object): the version counter is part of the fingerprint
+    m.inducing_variable.Z.mul_(0.9)
+    ref = fresh(0.9 * Z1, 1.7, [0.6, 1.4], 0.05)
+    assert relerr(m.predict_f(Xs)[0], ref.predict_f(Xs)[0].cpu().numpy()) < 1e-9
+    assert e0 != m.elbo()
