@@ -18,7 +18,7 @@ MGP_COMM_ID_BYTES = 128
 F32, F64 = 0, 1
 SE, MATERN12, MATERN32, MATERN52 = 0, 1, 2, 3
 COLS, ROWS = 0, 1
-PRE_EYE, PRE_JACOBI, PRE_BLOCK, PRE_DENSE = 0, 1, 2, 3
+PRE_EYE, PRE_JACOBI, PRE_BLOCK, PRE_DENSE, PRE_CALLBACK = 0, 1, 2, 3, 4
 OP_DENSE, OP_SGPR, OP_KMM_LAMBDA = 0, 1, 2
 
 KERNEL_KINDS = {"se": SE, "matern12": MATERN12, "matern32": MATERN32, "matern52": MATERN52}
@@ -68,6 +68,10 @@ class MgpOperator(ctypes.Structure):
     ]
 
 
+PRECOND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                              ctypes.c_int64, ctypes.c_void_p)
+
+
 class MgpPrecond(ctypes.Structure):
     _fields_ = [
         ("kind", ctypes.c_int32),
@@ -77,6 +81,10 @@ class MgpPrecond(ctypes.Structure):
         ("block_index", ctypes.c_void_p),
         ("block_inv", ctypes.c_void_p),
         ("dense_inv", ctypes.c_void_p),
+        ("apply", PRECOND_FN),
+        ("apply_ctx", ctypes.c_void_p),
+        ("cb_r", ctypes.c_void_p),
+        ("cb_z", ctypes.c_void_p),
     ]
 
 

@@ -175,8 +175,12 @@ class SgprNormalOperator(LinearOperator):
                 try:
                     # libmgp enqueued the partial on `stream` (its handle's stream == torch's current one,
                     # _hip.get_handle); make that explicit for the collective
-                    with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=buf.device)):
-                        self.allreduce(buf[:count])
+                    if stream:  # NULL = the legacy default stream, which is torch's default stream too
+                        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=buf.device)):
+                            self.allreduce(buf[:count])
+                    else:
+                        with torch.cuda.stream(torch.cuda.default_stream(buf.device)):
+                            self.allreduce(buf[:count])
                     return 0
                 except Exception:  # never let an exception cross the C boundary
                     import traceback
@@ -241,13 +245,46 @@ def as_operator(matrix):
 
 # --------------------------------------------------------------------------- preconditioners
 class CGPreconditioner:
-    """Protocol of reference :125-128.  Device preconditioners describe themselves to libmgp
-    through `_native(op)`; `__call__(vec, mat) -> (z, rz)` applies them eagerly (tests, users)."""
+    """Protocol of reference :125-128: `__call__(vec [Bt,n], mat) -> (z, rz)`.
+
+    The CG loop is device resident.  The preconditioners libmgp knows (Eye / Jacobi / Block / Dense)
+    describe themselves through `_native(op)` and run inside its kernels.  ANY OTHER subclass -- a user's
+    own `__call__`, as the reference allows -- is served through libmgp's callback kind: once per step the
+    library hands the residual batch over, `__call__(r, mat)` is run on the solve's stream (torch ops), and
+    its `z` goes back into the loop; `rz` is recomputed by the library exactly as `sum(z * r, -1)`."""
 
     def _native(self, op):
-        raise NotImplementedError(
-            "the CG loop is device resident: subclass one of Eye/Jacobi/BlockPreconditioner "
-            "(arbitrary Python callables cannot run inside it)")
+        return None
+
+    def _native_for(self, op, Bt):
+        nat = self._native(op)
+        if nat is not None:
+            return nat
+        n = op.shape[0]
+        r_buf = torch.empty((Bt, n), dtype=op.dtype, device=op.device)
+        z_buf = torch.empty_like(r_buf)
+        mat = op.A if isinstance(op, DenseOperator) else op  # what the reference passes as `mat` (:77,:89)
+
+        def _cb(ctx, r_ptr, z_ptr, bt, nn, stream):
+            try:
+                st = torch.cuda.ExternalStream(stream, device=r_buf.device) if stream else \
+                    torch.cuda.default_stream(r_buf.device)
+                with torch.cuda.stream(st):
+                    z = self(r_buf, mat)[0]
+                    z_buf.copy_(z.reshape(z_buf.shape))
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        fn = _hip.PRECOND_FN(_cb)
+        st = _hip.MgpPrecond()
+        st.kind = _hip.PRE_CALLBACK
+        st.apply = fn
+        st.cb_r = r_buf.data_ptr()
+        st.cb_z = z_buf.data_ptr()
+        return st, (r_buf, z_buf, fn, mat)
 
     def __call__(self, vec, mat):
         raise NotImplementedError
@@ -441,7 +478,7 @@ def _solve_device(op, rhs, initial_solution, error_threshold, preconditioner, ma
             op.reserve(Bt)
         hd = _hip.get_handle(op.device)
         st, keep = op._struct()
-        pst, pkeep = preconditioner._native(op)
+        pst, pkeep = preconditioner._native_for(op, Bt)
         hd.check(hd.lib.mgp_pcg_solve(
             hd.h, ctypes.byref(st), ctypes.byref(pst), _hip.ptr(rhs), _hip.ptr(v0), Bt,
             float(error_threshold), max_iterations, max_steps_cycle, float(min_float), int(check_every),

@@ -47,10 +47,11 @@ def oips_update_inducing_parameters(model, data, Z, allreduce=None):
     return Z, means[:, None], new_counts[:, None]
 
 
-def kmeans_update_inducing_parameters(model, data, distance_type, Z, allreduce=None):
-    """`optimize.py:81-98`: u = scatter_add(y) / counts, counts kept as they are."""
-    dt = {"euclidean": "euclidean", "covariance": "covariance", "correlation": "correlation",
-          None: "euclidean"}[distance_type]
+def kmeans_update_inducing_parameters(model, data, distance_fn, Z, allreduce=None):
+    """`optimize.py:81-98`: u = scatter_add(y) / counts, counts kept as they are.  `distance_fn` as the
+    reference takes it (None, `euclid_distance`, a `create_distance_fn` result) or the type as a string."""
+    from .distance import resolve_distance
+    dt, _ = resolve_distance(distance_fn, model.kernel)
     _, sums, counts = nearest_centre_statistics(model.kernel, Z, data, dt, allreduce)
     return Z, (sums / counts)[:, None], counts[:, None]
 

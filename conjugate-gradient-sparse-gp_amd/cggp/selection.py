@@ -13,28 +13,34 @@ import torch
 
 from . import ops
 
-_DIST = {None: "euclidean", "euclidean": "euclidean", "covariance": "covariance", "correlation": "correlation"}
+from .distance import resolve_distance
 
 
-def kmeans_indices_and_distances(centroids, points, distance_type=None, kernel=None):
-    """`selection.py:14-32`: index of the nearest centroid and the distance to it, per point."""
+def kmeans_indices_and_distances(centroids, points, distance_fn=None, kernel=None):
+    """`selection.py:14-32`: index of the nearest centroid and the distance to it, per point.
+    `distance_fn` as in the reference: None, `euclid_distance` or a `create_distance_fn(...)` result
+    (also accepted: the distance type as a string, with `kernel`)."""
     D = points.shape[1]
+    dtype_name, kernel = resolve_distance(distance_fn, kernel)
     if kernel is None:
         from .kernels import SquaredExponential
         kernel = SquaredExponential(1.0, [1.0] * D)  # unused by the euclidean distances
-    idx, dist = ops.nearest_center(kernel.spec(D), points, centroids, distance_type=_DIST[distance_type])
+    idx, dist = ops.nearest_center(kernel.spec(D), points, centroids, distance_type=dtype_name)
     return idx, dist
 
 
-def kmeans_lloyd(points, k_centroids, threshold=1e-5, initial_centroids=None, distance_type=None, kernel=None,
-                 seed=0, max_loops=10000):
-    """`selection.py:35-73`."""
+def kmeans_lloyd(points, k_centroids, threshold=1e-5, initial_centroids=None, distance_fn=None, kernel=None,
+                 seed=0, max_loops=10000, distance_type=None):
+    """`selection.py:35-73` (same positional order: points, k_centroids, threshold, initial_centroids,
+    distance_fn).  `distance_type=` is the build's older spelling of a string `distance_fn`."""
+    if distance_fn is None and distance_type is not None:
+        distance_fn = distance_type
     if initial_centroids is None:  # :65-67
         g = torch.Generator().manual_seed(seed)
         initial_centroids = points[torch.randperm(points.shape[0], generator=g)[:k_centroids].to(points.device)]
 
     def body(centroids):
-        idx, dist = kmeans_indices_and_distances(centroids, points, distance_type, kernel)  # :48-50
+        idx, dist = kmeans_indices_and_distances(centroids, points, distance_fn, kernel)  # :48-50
         # per-cluster coordinate sums in one pass, deterministic order (:58-63)
         sums, counts = ops.cluster_stats(idx, points, k_centroids)
         if sums.dim() == 1:  # one input dimension

@@ -20,6 +20,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
   const char* mode = getenv("MGP_SWEEP");
   if (mode && strcmp(mode, "mfma") == 0) h->sweep_mode = 1;
+  const char* sf = getenv("MGP_SWEEP_FAST");
+  if (sf && strcmp(sf, "0") == 0) h->sweep_fast = 0;
   const char* pm = getenv("MGP_CONTRACT_PANEL_MB");
   if (pm && atoi(pm) > 0) h->contract_panel_mb = (size_t)atoi(pm);
   const char* nz = getenv("MGP_CONTRACT_NZ");
@@ -74,7 +76,7 @@ extern "C" size_t mgp_workspace_bytes(const mgp_handle* h) {
   if (!h) return 0;
   if (h->pool) return h->pool_used;
   // 256 bytes of alignment slack per arena, as a fixed pool would spend
-  return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + 4 * 256;
+  return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + h->pack[0].bytes + h->pack[1].bytes + 6 * 256;
 }
 
 extern "C" int mgp_destroy(mgp_handle* h) {
@@ -87,6 +89,8 @@ extern "C" int mgp_destroy(mgp_handle* h) {
     if (h->cg) (void)hipFree(h->cg);
     if (h->opws) (void)hipFree(h->opws);
     if (h->gen) (void)hipFree(h->gen);
+    for (auto& ps : h->pack)
+      if (ps.buf) (void)hipFree(ps.buf);
   }
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);

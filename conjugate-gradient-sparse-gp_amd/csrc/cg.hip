@@ -450,8 +450,10 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   const long n = op->n;
   const long tot = Bt * n;
   const auto t0 = std::chrono::steady_clock::now();
+  PackHold pack_hold(h);  // the operator's X / Z / kernel are constant for the whole solve
   PrecondDev pc{MGP_PRE_EYE, 0, 0, nullptr, nullptr, nullptr};
   const void* dense_inv = nullptr;  // MGP_PRE_DENSE: z = r @ Pinv through the symmetric product kernels
+  const mgp_precond* cb = nullptr;  // MGP_PRE_CALLBACK: z produced by the caller's function, same step structure
   if (pre) {
     pc.kind = pre->kind;
     if (pre->kind == MGP_PRE_JACOBI) {
@@ -467,24 +469,38 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     } else if (pre->kind == MGP_PRE_DENSE) {
       if (!pre->dense_inv) return mgp_fail(h, MGP_E_BADARG, "dense preconditioner without matrix");
       dense_inv = pre->dense_inv;
+    } else if (pre->kind == MGP_PRE_CALLBACK) {
+      if (!pre->apply || !pre->cb_r || !pre->cb_z)
+        return mgp_fail(h, MGP_E_BADARG, "callback preconditioner needs apply, cb_r and cb_z");
+      cb = pre;
     } else if (pre->kind != MGP_PRE_EYE) {
       return mgp_fail(h, MGP_E_BADARG, "unknown preconditioner kind %d", pre->kind);
     }
   }
-  const bool dense_pre = dense_inv != nullptr;
-  const bool need_z = pc.kind != MGP_PRE_EYE;  // dense included: z = r @ Pinv lives in memory
-  if (dense_pre) pc.kind = MGP_PRE_EYE;        // the update kernels never apply it themselves
+  const bool dense_pre = dense_inv != nullptr || cb != nullptr;  // z comes from outside the update kernels
+  const bool need_z = pc.kind != MGP_PRE_EYE && cb == nullptr;   // dense: z = r @ Pinv lives in the arena
+  if (dense_pre) pc.kind = MGP_PRE_EYE;                          // the update kernels never apply it themselves
   // arena: r, p, ap, [z], rz[Bt], over[Bt] (int), ctrl
   size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64;
   MGP_TRY(mgp_reserve(h, &h->cg, &h->cg_bytes, bytes));
   T* r = (T*)h->cg;
   T* p = r + tot;
   T* ap = p + tot;
-  T* z = need_z ? ap + tot : nullptr;
-  T* rz = (need_z ? z : ap) + tot;
+  T* z = need_z ? ap + tot : (cb ? (T*)cb->cb_z : nullptr);
+  T* rz = (need_z ? ap + tot : ap) + tot;
   int* over = (int*)(rz + Bt);
   CgCtrl* ctrl = (CgCtrl*)(((uintptr_t)(over + Bt) + 15) & ~(uintptr_t)15);
   hipStream_t s = h->stream;
+  // z = M^-1 r for the preconditioners applied outside the update kernels
+  auto external_z = [&](const int* gate) -> int {
+    if (cb) {
+      MGP_HIP(h, hipMemcpyAsync(cb->cb_r, r, (size_t)tot * sizeof(T), hipMemcpyDeviceToDevice, s));
+      const int rc = cb->apply(cb->apply_ctx, cb->cb_r, cb->cb_z, Bt, n, (void*)s);
+      if (rc != 0) return mgp_fail(h, MGP_E_BADARG, "preconditioner callback returned %d", rc);
+      return MGP_OK;
+    }
+    return mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, gate);
+  };
 
   MGP_HIP(h, hipMemsetAsync(ctrl, 0, sizeof(CgCtrl), s));
   const T* av = nullptr;
@@ -502,7 +518,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   } else {  // r = b - vA ; z = r @ Pinv ; p = z, rz = z.r, flags
     hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, av, r, tot, 1);
     MGP_LAUNCH_CHECK(h);
-    MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, nullptr));
+    MGP_TRY(external_z(nullptr));
     hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz, over,
                        err_out, n, (T)thr, (T)min_float, pc, 5, 1);
     MGP_LAUNCH_CHECK(h);
@@ -559,7 +575,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
           hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 3, 0);
           MGP_LAUNCH_CHECK(h);
-          MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, &ctrl->active));
+          MGP_TRY(external_z(&ctrl->active));
           hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 4, 0);
         }
@@ -570,7 +586,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
         MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, &ctrl->active));
         hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot, 0);
         MGP_LAUNCH_CHECK(h);
-        if (dense_pre) MGP_TRY(mgp_symm_matmul_gated(h, op->dtype, dense_inv, n, r, Bt, z, &ctrl->active));
+        if (dense_pre) MGP_TRY(external_z(&ctrl->active));
         hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, dense_pre ? 5 : 2, 0);
       }

@@ -28,6 +28,20 @@ struct mgp_handle {
   // generic-D scratch (transposed multipliers, kernel panel, chunk output)
   void* gen = nullptr;
   size_t gen_bytes = 0;
+  // packed streamed points of the fp64 SE fast sweep (sweep.hip).  Two slots: a solve alternates the K_nm
+  // direction (streamed set Z) and the K_mn direction (streamed set X).  A pack is reused only while
+  // `pack_hold` is set -- inside mgp_pcg_solve, where the operator's X, Z and kernel cannot change.
+  struct PackSlot {
+    void* buf = nullptr;
+    size_t bytes = 0;
+    const void* src = nullptr;
+    long n = 0;
+    int D = 0;
+    double inv_ls[MGP_FUSED_MAX_D] = {0};
+    bool valid = false;
+  } pack[2];
+  int pack_next = 0;
+  bool pack_hold = false;
   // mgp_create_ex: one caller-sized block that serves every arena above; no hipMalloc/hipFree after create
   void* pool = nullptr;
   size_t pool_bytes = 0, pool_used = 0;
@@ -39,6 +53,9 @@ struct mgp_handle {
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
   int sweep_mode = 0;
+  // fp64 SE, D <= 8, one right-hand side: 1 = sweep_se_fast_kernel (scalar-loaded packed points, integer
+  // exponent scaling), 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST=0, for A/B runs)
+  int sweep_fast = 1;
   // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
   // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)
   size_t contract_panel_mb = 2048;
@@ -54,6 +71,19 @@ struct mgp_handle {
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
+};
+
+// scope guard of mgp_pcg_solve: packs made during the solve are reused by its later iterations
+struct PackHold {
+  mgp_handle* h;
+  explicit PackHold(mgp_handle* hh) : h(hh) {
+    h->pack[0].valid = h->pack[1].valid = false;
+    h->pack_hold = true;
+  }
+  ~PackHold() {
+    h->pack_hold = false;
+    h->pack[0].valid = h->pack[1].valid = false;
+  }
 };
 
 // returns the stop event to record after the launch (nullptr when profiling is off)

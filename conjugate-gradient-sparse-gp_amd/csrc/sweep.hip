@@ -14,6 +14,8 @@
 //   D fma (2 a.b - |a|^2 - |b|^2, GPflow's square_distance expansion)  +  profile  +  RC fma
 // with all LDS reads being wave-uniform broadcasts (conflict free).  The kernel is bound by
 // fp64 VALU issue, not HBM: algorithmic bytes are s(ND + MD + MR + NR).
+#include <type_traits>
+
 #include "mgp_common.h"
 
 namespace {
@@ -231,6 +233,213 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
   }
 }
 
+
+// ---- fp64 squared-exponential fast path (D <= 8, one right-hand side: the CG case) -------------
+// Same arithmetic as the FAST branch of sweep_kernel, re-laid-out for the issue ports of a CDNA4
+// CU (profiles/r02_valu_issue_probe.txt: a VALU-bound loop pays ~0.7-0.8 of an fp64 slot for every
+// 32-bit integer op and for every per-lane LDS gather, and nothing for scalar loads):
+//   * streamed points are packed once (pack_points_kernel: 2 c b/l and -|c b/l|^2, DP+1 doubles)
+//     and read by SCALAR loads, double-buffered in SGPRs: no LDS tile, no barrier, no broadcast
+//     ds_read, no VGPRs spent on them -- the fma takes the SGPR pair as its operand;
+//   * 2^n is applied by ONE integer add on the high word of the gathered table entry: the table
+//     holds T'[i] = T[i] with (i << 9) subtracted from its high word, so hi + (m << 9) =
+//     hi(T[i]) + (n << 20) for m = 2048 n + i (replaces v_ldexp_f64 + v_ashrrev_i32);
+//   * LDS holds only the 16 KB table.
+// Per pair: D fma + 3 add (magic) + 2 fma + mul + fma (polynomial, table) + fma (accumulate)
+// = D + 8 fp64 and 3 integer instructions (and, lshl, lshl_add), one ds_read_b64 gather.
+// Valid while the exponent stays normal: t = -|a-b|^2 >= -2(|a|^2+|b|^2) > -1000 (scaled units),
+// checked per workgroup against the packed set's maximum norm; otherwise, and for NaN inputs, the
+// clamped variant of the same loop runs (2^-1000 stands for 0; NaN stays NaN).
+constexpr double kFastLimit = 1000.0;
+
+template <int DP>
+__global__ __launch_bounds__(256) void pack_points_kernel(const double* __restrict__ B, long nb, int D,
+                                                          SweepParams prm, double* __restrict__ P,
+                                                          unsigned long long* __restrict__ bmax_bits) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  double s = 0;
+  if (j < nb) {
+    double* p = P + j * (DP + 1);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const double v = d < D ? B[j * D + d] * prm.inv_ls[d] : 0.0;
+      s = mgp_fma(v, v, s);
+      p[d] = v + v;
+    }
+    p[DP] = -s;
+  }
+  // max |b|^2 of the whole set (bit pattern of a non-negative double orders like the value; a NaN
+  // pattern is larger than every number, so a NaN point makes the set "unsafe")
+  unsigned long long bits = __builtin_bit_cast(unsigned long long, s) & 0x7fffffffffffffffULL;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(bits, off, 64);
+    bits = o > bits ? o : bits;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(bmax_bits, bits);
+}
+
+template <int DP, int RPT>
+__global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kernel(
+    const double* __restrict__ A, long na, const double* __restrict__ Pk, long nb, long b_chunk,
+    const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_chunk, int D,
+    SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, const int* __restrict__ gate,
+    int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits) {
+  if (gate != nullptr && *gate == 0) return;
+  const int lin = blockIdx.x;
+  int bx, by;
+  if ((nchunks & 7) == 0) {  // XCD-aware decode, as sweep_kernel
+    const int grp = lin / (8 * nblk), rem = lin - grp * (8 * nblk);
+    bx = rem >> 3;
+    by = grp * 8 + (rem & 7);
+  } else {
+    by = lin / nblk;
+    bx = lin - by * nblk;
+  }
+  __shared__ double e2tab[MGP_EXP2_TAB_SIZE];
+  __shared__ double amax_w[kThreads / 64];
+  const int t = threadIdx.x;
+  for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreads) {
+    unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2_tab_entry(e));
+    bits -= (unsigned long long)e << (9 + 32);  // high word -= e << 9
+    e2tab[e] = __builtin_bit_cast(double, bits);
+  }
+  const long base = (long)bx * (kThreads * RPT);
+  double a[RPT][DP], cq[RPT], acc[RPT];
+  double amax = 0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    long i = base + q * kThreads + t;
+    if (i >= na) i = na - 1;  // clamp: computed but never stored
+    double s = 0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const double v = d < D ? A[i * D + d] * prm.inv_ls[d] : 0.0;
+      a[q][d] = v;
+      s = mgp_fma(v, v, s);
+    }
+    amax = s > amax ? s : amax;  // a NaN norm is not taken here; it reaches the result through cq
+    cq[q] = MGP_EXP2_MAGIC - s;  // rounded to a multiple of 2^-11
+    acc[q] = 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(amax, off, 64);
+    amax = o > amax ? o : amax;
+  }
+  if ((t & 63) == 0) amax_w[t >> 6] = amax;
+  __syncthreads();  // table + amax_w
+  double aa = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) aa = amax_w[w] > aa ? amax_w[w] : aa;
+  const double bb = __builtin_bit_cast(double, *bmax_bits);
+  const bool safe = 2.0 * (aa + bb) < kFastLimit;  // NaN compares false -> clamped loop
+
+  const long jb = (long)by * b_chunk;
+  const long je = (jb + b_chunk < nb) ? jb + b_chunk : nb;
+  const double C1 = 0x1.62e42fefa39efp-1, C2 = 0x1.ebfbdff82c58fp-3, C3 = 0x1.c6b08d704a0c0p-5;  // ln2^k / k!
+
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const char* tab_bytes = (const char*)e2tab;
+  // One streamed point against the RPT owned points, in three phases so that the table gathers of all
+  // RPT pairs are in flight while the polynomial is evaluated (one LDS wait per point, not per pair).
+  auto pair_step = [&](auto clamp_tag, const double (&b)[DP], double nb2, double w) {
+    constexpr bool CLAMP = decltype(clamp_tag)::value;
+    double g[RPT], tq[RPT];
+    unsigned ex[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      double s = nb2;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
+      double u = s + cq[q];
+      bool low = false;
+      if (CLAMP) {
+        const double cmin = MGP_EXP2_MAGIC - kFastLimit;
+        low = u < cmin;  // false for NaN: NaN flows on
+        u = low ? cmin : u;
+      }
+      const unsigned m = __builtin_bit_cast(u32x2, u).x;  // round(2048 t) in two's complement
+      const double gg = s - (u - cq[q]);
+      g[q] = CLAMP ? (low ? 0.0 : gg) : gg;
+      // byte offset of table entry m & 2047 and the exponent increment (m << 9 on the high word): pinned
+      // as three 32-bit instructions (left to itself the compiler packs pairs of indices with v_perm and
+      // widens the exponent add to 64 bits: ~7 integer instructions per pair instead of 3)
+      unsigned off;
+      asm("v_lshlrev_b32 %0, 3, %1\n\tv_and_b32 %0, 0x3ff8, %0" : "=&v"(off) : "v"(m));
+      ex[q] = m;
+      tq[q] = *(const double*)(tab_bytes + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double pq[RPT];  // stage-major: RPT independent chains back to back, no dependent-issue stall
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) pq[q] = mgp_fma(g[q], C3, C2);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) pq[q] = mgp_fma(pq[q], g[q], C1);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) pq[q] = pq[q] * g[q];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      u32x2 tb = __builtin_bit_cast(u32x2, tq[q]);
+      asm("v_lshl_add_u32 %0, %1, 9, %0" : "+v"(tb.y) : "v"(ex[q]));  // hi(T') + (m << 9) = hi(T) + (n << 20)
+      const double T2 = __builtin_bit_cast(double, tb);
+      const double kv = mgp_fma(T2, pq[q], T2);
+      acc[q] = mgp_fma(kv, w, acc[q]);
+    }
+  };
+  auto sweep_loop = [&](auto clamp_tag) {
+    // scalar double buffering over the chunk [jb, je): the row of the next point is requested before the
+    // current one is consumed; pointers are bumped (no 64-bit index multiplies), the count is 32-bit
+    const double* rp = Pk + jb * (DP + 1);
+    const double* wp = W + jb * w_sj;
+    int rem = (int)(je - jb);
+    auto load = [&](const double* r, const double* wq, bool live, double (&b)[DP], double& nb2, double& w) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) b[d] = r[d];
+      nb2 = r[DP];
+      const double wv = *wq;
+      w = live ? wv : 0.0;
+    };
+    double b0[DP], b1[DP], n0, n1, w0, w1;
+    load(rp, wp, true, b0, n0, w0);
+    while (rem > 0) {
+      const bool m1 = rem > 1, m2 = rem > 2;
+      const double* r1 = m1 ? rp + (DP + 1) : rp;
+      const double* q1 = m1 ? wp + w_sj : wp;
+      load(r1, q1, m1, b1, n1, w1);
+      pair_step(clamp_tag, b0, n0, w0);
+      const double* r2 = m2 ? r1 + (DP + 1) : r1;
+      const double* q2 = m2 ? q1 + w_sj : q1;
+      load(r2, q2, m2, b0, n0, w0);
+      pair_step(clamp_tag, b1, n1, w1);
+      rp = r2;
+      wp = q2;
+      rem -= 2;
+    }
+  };
+  if (jb < je) {
+    if (safe)
+      sweep_loop(std::false_type{});
+    else
+      sweep_loop(std::true_type{});
+  }
+
+  double* o = out + (long)by * o_chunk;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const long i = base + q * kThreads + t;
+    if (i < na) {
+      double a2 = 0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) a2 = mgp_fma(a[q][d], a[q][d], a2);
+      double v = prm.variance * acc[q] * mgp_exp2((MGP_EXP2_MAGIC - cq[q]) - a2);  // 2^rho
+      if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si], v);
+      o[i * o_si] = v;
+    }
+  }
+}
+
 // out(i,r) = sum_c partial[c][r][i] (+ alpha*addend).  Block = 16 groups x 64 columns: group g
 // sums chunks g, g+16, ... in index order, the 16 group sums are added in a fixed tree -- the
 // result does not depend on scheduling (deterministic, no float atomics).
@@ -284,6 +493,60 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   if (nchunks > 65535) return mgp_fail(h, MGP_E_SHAPE, "sweep: too many chunks");
   if (nblk * nchunks > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "sweep: grid too large");
   dim3 grid((unsigned)(nblk * nchunks));
+  if constexpr (std::is_same<T, double>::value && KIND == 0 && DP <= 8 && RC == 1 && !SQ) {
+    if (h->sweep_fast) {
+      // packed streamed set: reused across the iterations of a solve (pack_hold), else rebuilt
+      mgp_handle::PackSlot* ps = nullptr;
+      if (h->pack_hold)
+        for (auto& c : h->pack)
+          if (c.valid && c.src == (const void*)B && c.n == nb && c.D == D &&
+              memcmp(c.inv_ls, prm.inv_ls, sizeof(c.inv_ls)) == 0)
+            ps = &c;
+      if (!ps) {
+        ps = &h->pack[h->pack_next];
+        h->pack_next ^= 1;
+        ps->valid = false;
+        MGP_TRY(mgp_reserve(h, &ps->buf, &ps->bytes, 64 + (size_t)nb * (DP + 1) * sizeof(double)));
+        MGP_HIP(h, hipMemsetAsync(ps->buf, 0, 64, h->stream));
+        hipLaunchKernelGGL((pack_points_kernel<DP>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, B,
+                           nb, D, prm, (double*)((char*)ps->buf + 64), (unsigned long long*)ps->buf);
+        MGP_LAUNCH_CHECK(h);
+        ps->src = (const void*)B;
+        ps->n = nb;
+        ps->D = D;
+        memcpy(ps->inv_ls, prm.inv_ls, sizeof(ps->inv_ls));
+        ps->valid = h->pack_hold;
+      }
+      const double* Pk = (const double*)((char*)ps->buf + 64);
+      const unsigned long long* bmax = (const unsigned long long*)ps->buf;
+      T* dst = out;
+      long d_si = o_si, d_chunk = 0;
+      T a_alpha = alpha;
+      const T* a_add = addend;
+      long a_si = ad_si;
+      if (nchunks > 1) {
+        MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nchunks * na * sizeof(T)));
+        dst = (T*)h->ws;
+        d_si = 1;
+        d_chunk = na;
+        a_alpha = 0;
+        a_add = nullptr;
+        a_si = 0;
+      }
+      hipEvent_t stop = mgp_prof_begin(h);
+      hipLaunchKernelGGL((sweep_se_fast_kernel<DP, TileCfg<DP>::RPT>), grid, dim3(kThreads), 0, h->stream, A, na, Pk,
+                         nb, b_chunk, W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk,
+                         (int)nchunks, bmax);
+      mgp_prof_end(h, stop);
+      MGP_LAUNCH_CHECK(h);
+      if (nchunks > 1) {
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((na + 63) / 64)), dim3(1024), 0, h->stream,
+                           (const T*)h->ws, na, 1, (int)nchunks, out, o_si, o_sr, alpha, addend, ad_si, ad_sr, gate);
+        MGP_LAUNCH_CHECK(h);
+      }
+      return MGP_OK;
+    }
+  }
   if (nchunks == 1) {
     hipEvent_t stop = mgp_prof_begin(h);
     hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC, SQ>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,

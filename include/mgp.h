@@ -51,7 +51,7 @@ enum { MGP_SE = 0, MGP_MATERN12 = 1, MGP_MATERN32 = 2, MGP_MATERN52 = 3 };
  * function-level layout of conjugate_gradient(), conjugate_gradient.py:24-32). */
 enum { MGP_COLS = 0, MGP_ROWS = 1 };
 
-enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2, MGP_PRE_DENSE = 3 };
+enum { MGP_PRE_EYE = 0, MGP_PRE_JACOBI = 1, MGP_PRE_BLOCK = 2, MGP_PRE_DENSE = 3, MGP_PRE_CALLBACK = 4 };
 
 enum { MGP_OP_DENSE = 0, MGP_OP_SGPR = 1, MGP_OP_KMM_LAMBDA = 2 };
 
@@ -113,6 +113,15 @@ typedef struct {
   int32_t world_size; int32_t reserved;
 } mgp_operator;
 
+/* MGP_PRE_CALLBACK: the caller's own preconditioner, the protocol of CGPreconditioner.__call__(vec, mat)
+ * (conjugate_gradient.py:125-128, used at :77,:89).  Once per CG step, between the two halves of the
+ * update, the library copies the residual batch r [Bt, n] into `cb_r` and calls `apply`, which must
+ * ENQUEUE on `stream` work that leaves z = M^-1 r in `cb_z` (both buffers caller-owned device memory);
+ * rz = sum(z * r) is formed by the library (the reference recomputes it the same way).  The loop stays
+ * device resident: steps enqueued past convergence are gated off and their z is ignored.  Non-zero
+ * return aborts the solve with MGP_E_BADARG. */
+typedef int (*mgp_precond_fn)(void* ctx, const void* r, void* z, int64_t Bt, int64_t n, void* stream);
+
 typedef struct {
   int32_t kind;               /* MGP_PRE_* */
   int32_t block_size;         /* MGP_PRE_BLOCK: bs */
@@ -121,6 +130,10 @@ typedef struct {
   const int64_t* block_index; /* MGP_PRE_BLOCK: [nb, bs] int64 device */
   const void* block_inv;      /* MGP_PRE_BLOCK: inverse of A[idx,idx], [nb, bs, bs] device */
   const void* dense_inv;      /* MGP_PRE_DENSE: symmetric P^-1 [n, n] device; z = r @ P^-1 */
+  mgp_precond_fn apply;       /* MGP_PRE_CALLBACK */
+  void* apply_ctx;
+  void* cb_r;                 /* MGP_PRE_CALLBACK: [Bt, n] device, receives r before every call */
+  void* cb_z;                 /* MGP_PRE_CALLBACK: [Bt, n] device, z left there by `apply` */
 } mgp_precond;
 
 typedef struct {

@@ -45,7 +45,7 @@ def test_version_arch_and_struct_layout(lib):
     # struct sizes the C side compiles to (LP64): keeps the ctypes mirror honest
     assert ctypes.sizeof(_hip.MgpKernel) == 4 * 4 + 8 + 8 * _hip.MGP_MAX_D
     assert ctypes.sizeof(_hip.MgpOperator) == 8 + 8 + 8 * 14 + 8 + 8
-    assert ctypes.sizeof(_hip.MgpPrecond) == 8 + 8 + 8 * 4
+    assert ctypes.sizeof(_hip.MgpPrecond) == 8 + 8 + 8 * 4 + 8 * 4
     assert ctypes.sizeof(_hip.MgpCgStats) == 16
 
 
@@ -71,7 +71,8 @@ int main(void) {
   F(mgp_operator, partial_buf); F(mgp_operator, kmm_row_begin); F(mgp_operator, kmm_row_end); F(mgp_operator, comm);
   F(mgp_operator, world_size); F(mgp_operator, reserved);
   F(mgp_precond, kind); F(mgp_precond, block_size); F(mgp_precond, num_blocks); F(mgp_precond, diag_inv);
-  F(mgp_precond, block_index); F(mgp_precond, block_inv); F(mgp_precond, dense_inv);
+  F(mgp_precond, block_index); F(mgp_precond, block_inv); F(mgp_precond, dense_inv); F(mgp_precond, apply);
+  F(mgp_precond, apply_ctx); F(mgp_precond, cb_r); F(mgp_precond, cb_z);
   F(mgp_cg_stats, iterations); F(mgp_cg_stats, converged); F(mgp_cg_stats, seconds);
   return 0;
 }
@@ -114,7 +115,7 @@ def test_header_compiles_as_c_and_matches_the_ctypes_mirror(lib, tmp_path):
             st, field = key.split(".")
             assert getattr(mirror[st], rename.get(field, field)).offset == val, key
             checked += 1
-    assert checked == 4 + 6 + 20 + 7 + 3
+    assert checked == 4 + 6 + 20 + 11 + 3
     # and the other direction: the mirror declares no field the header does not have
     for st, cls in mirror.items():
         for fname, _ in cls._fields_:
