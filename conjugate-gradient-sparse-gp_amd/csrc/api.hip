@@ -21,7 +21,13 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   const char* mode = getenv("MGP_SWEEP");
   if (mode && strcmp(mode, "mfma") == 0) h->sweep_mode = 1;
   const char* sf = getenv("MGP_SWEEP_FAST");
-  if (sf && strcmp(sf, "0") == 0) h->sweep_fast = 0;
+  if (sf && (strcmp(sf, "0") == 0 || strcmp(sf, "1") == 0 || strcmp(sf, "2") == 0)) h->sweep_fast = atoi(sf);
+  const char* pt = getenv("MGP_PF_TRIPS");
+  if (pt && atoi(pt) >= 1 && (atoi(pt) & (atoi(pt) - 1)) == 0) h->pf_trips = atoi(pt);
+  const char* pa = getenv("MGP_PF_AHEAD");
+  if (pa && atoi(pa) >= 0) h->pf_ahead = atoi(pa);
+  const char* fr = getenv("MGP_SWEEP_RPT");
+  if (fr && atoi(fr) >= 2 && atoi(fr) <= 4) h->sweep_fast_rpt = atoi(fr);
   const char* pm = getenv("MGP_CONTRACT_PANEL_MB");
   if (pm && atoi(pm) > 0) h->contract_panel_mb = (size_t)atoi(pm);
   const char* nz = getenv("MGP_CONTRACT_NZ");

@@ -53,9 +53,12 @@ struct mgp_handle {
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
   int sweep_mode = 0;
-  // fp64 SE, D <= 8, one right-hand side: 1 = sweep_se_fast_kernel (scalar-loaded packed points, integer
-  // exponent scaling), 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST=0, for A/B runs)
-  int sweep_fast = 1;
+  // fp64 SE, D <= 8, one right-hand side: sweep_se_fast_kernel (scalar-loaded packed points, integer exponent
+  // scaling) with 1 = 256 threads / 2048-entry table, 2 = 512 threads / 8192-entry table and a one-instruction
+  // table offset; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
+  int sweep_fast = 2;
+  int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
+  int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
   // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
   // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)
   size_t contract_panel_mb = 2048;

@@ -279,12 +279,16 @@ __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restri
   if ((threadIdx.x & 63) == 0) atomicMax(bmax_bits, bits);
 }
 
-template <int DP, int RPT>
-__global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kernel(
+// NT threads per workgroup share one table of 2^TBITS entries (t = m / 2^TBITS + g, |g| <= 2^-(TBITS+1)):
+//   TBITS 11, NT 256: 16 KB, four workgroups per CU; byte offset of the entry by shift + and;
+//   TBITS 13, NT 512: 64 KB, two workgroups per CU; the offset is ONE instruction -- an SDWA shift that
+//   keeps the low 16 bits of (m << 3), i.e. (m & 8191) * 8 -- so a pair costs D + 8 fp64 + 2 integer.
+template <int DP, int RPT, int NT, int TBITS>
+__global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_se_fast_kernel(
     const double* __restrict__ A, long na, const double* __restrict__ Pk, long nb, long b_chunk,
     const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_chunk, int D,
     SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, const int* __restrict__ gate,
-    int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits) {
+    int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits, int pf_mask, int pf_ahead) {
   if (gate != nullptr && *gate == 0) return;
   const int lin = blockIdx.x;
   int bx, by;
@@ -296,20 +300,23 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
     by = lin / nblk;
     bx = lin - by * nblk;
   }
-  __shared__ double e2tab[MGP_EXP2_TAB_SIZE];
-  __shared__ double amax_w[kThreads / 64];
+  constexpr int TSIZE = 1 << TBITS;
+  constexpr double MAGIC = TBITS == 11 ? 0x1.8p+41 : 0x1.8p+39;  // ulp = 2^-TBITS: low word of t + MAGIC = round(2^TBITS t)
+  static_assert(TBITS == 11 || TBITS == 13, "table sizes: 2048 or 8192 entries");
+  __shared__ double e2tab[TSIZE];
+  __shared__ double amax_w[NT / 64];
   const int t = threadIdx.x;
-  for (int e = t; e < MGP_EXP2_TAB_SIZE; e += kThreads) {
-    unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2_tab_entry(e));
-    bits -= (unsigned long long)e << (9 + 32);  // high word -= e << 9
+  for (int e = t; e < TSIZE; e += NT) {
+    unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2((double)e * (1.0 / TSIZE)));
+    bits -= (unsigned long long)e << (20 - TBITS + 32);  // high word -= e << (20 - TBITS)
     e2tab[e] = __builtin_bit_cast(double, bits);
   }
-  const long base = (long)bx * (kThreads * RPT);
+  const long base = (long)bx * (NT * RPT);
   double a[RPT][DP], cq[RPT], acc[RPT];
   double amax = 0;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
-    long i = base + q * kThreads + t;
+    long i = base + q * NT + t;
     if (i >= na) i = na - 1;  // clamp: computed but never stored
     double s = 0;
 #pragma unroll
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
       s = mgp_fma(v, v, s);
     }
     amax = s > amax ? s : amax;  // a NaN norm is not taken here; it reaches the result through cq
-    cq[q] = MGP_EXP2_MAGIC - s;  // rounded to a multiple of 2^-11
+    cq[q] = MAGIC - s;  // rounded to a multiple of 2^-TBITS
     acc[q] = 0;
   }
 #pragma unroll
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
   __syncthreads();  // table + amax_w
   double aa = 0;
 #pragma unroll
-  for (int w = 0; w < kThreads / 64; ++w) aa = amax_w[w] > aa ? amax_w[w] : aa;
+  for (int w = 0; w < NT / 64; ++w) aa = amax_w[w] > aa ? amax_w[w] : aa;
   const double bb = __builtin_bit_cast(double, *bmax_bits);
   const bool safe = 2.0 * (aa + bb) < kFastLimit;  // NaN compares false -> clamped loop
 
@@ -355,18 +362,23 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
       double u = s + cq[q];
       bool low = false;
       if (CLAMP) {
-        const double cmin = MGP_EXP2_MAGIC - kFastLimit;
+        const double cmin = MAGIC - kFastLimit;
         low = u < cmin;  // false for NaN: NaN flows on
         u = low ? cmin : u;
       }
-      const unsigned m = __builtin_bit_cast(u32x2, u).x;  // round(2048 t) in two's complement
+      const unsigned m = __builtin_bit_cast(u32x2, u).x;  // round(2^TBITS t) in two's complement
       const double gg = s - (u - cq[q]);
       g[q] = CLAMP ? (low ? 0.0 : gg) : gg;
-      // byte offset of table entry m & 2047 and the exponent increment (m << 9 on the high word): pinned
+      // byte offset of table entry m & (2^TBITS - 1) and the exponent increment (on the high word): pinned
       // as three 32-bit instructions (left to itself the compiler packs pairs of indices with v_perm and
       // widens the exponent add to 64 bits: ~7 integer instructions per pair instead of 3)
       unsigned off;
-      asm("v_lshlrev_b32 %0, 3, %1\n\tv_and_b32 %0, 0x3ff8, %0" : "=&v"(off) : "v"(m));
+      if (TBITS == 11)
+        asm("v_lshlrev_b32 %0, 3, %1\n\tv_and_b32 %0, 0x3ff8, %0" : "=&v"(off) : "v"(m));
+      else  // low 16 bits of (m << 3), zero padded: (m & 8191) * 8
+        asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+            : "=v"(off)
+            : "v"(m));
       ex[q] = m;
       tq[q] = *(const double*)(tab_bytes + off);
     }
@@ -382,7 +394,11 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       u32x2 tb = __builtin_bit_cast(u32x2, tq[q]);
-      asm("v_lshl_add_u32 %0, %1, 9, %0" : "+v"(tb.y) : "v"(ex[q]));  // hi(T') + (m << 9) = hi(T) + (n << 20)
+      // hi(T') + (m << (20 - TBITS)) = hi(T) + (n << 20)
+      if (TBITS == 11)
+        asm("v_lshl_add_u32 %0, %1, 9, %0" : "+v"(tb.y) : "v"(ex[q]));
+      else
+        asm("v_lshl_add_u32 %0, %1, 7, %0" : "+v"(tb.y) : "v"(ex[q]));
       const double T2 = __builtin_bit_cast(double, tb);
       const double kv = mgp_fma(T2, pq[q], T2);
       acc[q] = mgp_fma(kv, w, acc[q]);
@@ -403,7 +419,25 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
     };
     double b0[DP], b1[DP], n0, n1, w0, w1;
     load(rp, wp, true, b0, n0, w0);
+    // The scalar loads run only ~half a trip ahead: enough for rows that sit in L2 (Z: 300 KB), not for rows
+    // that come from HBM (the K_mn direction streams X).  So every pf_mask+1 trips each lane touches one
+    // 128-byte line of the packed rows pf_ahead bytes further on (a vector load whose result is never
+    // used: it only pulls the lines into this XCD's L2 before the scalar loads ask for them).
+    const char* pf_end = (const char*)(Pk + (je - 1) * (DP + 1));
+    int trip = 0;
+    unsigned pf_sink = 0;
     while (rem > 0) {
+      if ((trip++ & pf_mask) == 0) {
+        // lane id recomputed here (two v_mbcnt) rather than kept live across the loop: the loop is at the
+        // register limit of its occupancy
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const char* pa = (const char*)rp + pf_ahead + lane * 128;
+        pa = pa < pf_end ? pa : pf_end;
+        // the value is looked at only when the NEXT prefetch is issued (kPfTrips trips later, long after it
+        // has landed), so the compiler's vmcnt wait for it costs nothing and the loop body never stalls on it
+        asm volatile("" ::"v"(pf_sink));
+        pf_sink = *(const unsigned*)pa;
+      }
       const bool m1 = rem > 1, m2 = rem > 2;
       const double* r1 = m1 ? rp + (DP + 1) : rp;
       const double* q1 = m1 ? wp + w_sj : wp;
@@ -417,6 +451,7 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
       wp = q2;
       rem -= 2;
     }
+    asm volatile("" ::"v"(pf_sink));  // the last prefetch is consumed here
   };
   if (jb < je) {
     if (safe)
@@ -428,12 +463,12 @@ __global__ __launch_bounds__(kThreads, RPT >= 4 ? 4 : 8) void sweep_se_fast_kern
   double* o = out + (long)by * o_chunk;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
-    const long i = base + q * kThreads + t;
+    const long i = base + q * NT + t;
     if (i < na) {
       double a2 = 0;
 #pragma unroll
       for (int d = 0; d < DP; ++d) a2 = mgp_fma(a[q][d], a[q][d], a2);
-      double v = prm.variance * acc[q] * mgp_exp2((MGP_EXP2_MAGIC - cq[q]) - a2);  // 2^rho
+      double v = prm.variance * acc[q] * mgp_exp2((MAGIC - cq[q]) - a2);  // 2^rho
       if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si], v);
       o[i * o_si] = v;
     }
@@ -477,13 +512,20 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
                  const T* W, long w_sj, long w_sr, T* out, long o_si, long o_sr, T alpha, const T* addend,
                  long ad_si, long ad_sr, const int* gate) {
   constexpr int TB = TileCfg<DP>::TB;
-  constexpr int RPT = TileCfg<DP>::RPT;
-  const long per_block = (long)kThreads * RPT;
+  constexpr bool kFastEligible = std::is_same<T, double>::value && KIND == 0 && DP <= 8 && RC == 1 && !SQ;
+  const int frpt = (kFastEligible && h->sweep_fast) ? h->sweep_fast_rpt : 0;  // owned points per lane, fast path
+  const int RPT = frpt ? frpt : TileCfg<DP>::RPT;
+  const int fnt = (frpt && h->sweep_fast == 2) ? 512 : kThreads;  // sweep_fast 2: 512 threads share an 8192-entry table
+  const long per_block = (long)fnt * RPT;
   const long nblk = (na + per_block - 1) / per_block;
   // enough workgroups to fill the chip: none of the streamed set is split when the owned side
   // already gives >= 4 workgroups per CU, else aim for ~8 per CU
   const long target = 8L * h->num_cus;
-  long nchunks = nblk >= (long)h->nosplit_per_cu * h->num_cus ? 1 : (target + nblk - 1) / nblk;
+  // The fast kernel splits the streamed set while the owned side gives fewer than 8 (256-thread-equivalent)
+  // workgroups per CU: with exactly one resident round (C3's K_nm.v: 4 per CU) the slowest CU sets the time
+  // (measured 2.41 -> 2.26 ms with two chunks); the LDS-tile kernels keep the round-1 threshold
+  const long nosplit = frpt ? (h->nosplit_per_cu > 8 ? h->nosplit_per_cu : 8) : h->nosplit_per_cu;
+  long nchunks = nblk * (fnt / kThreads) >= nosplit * h->num_cus ? 1 : (target + nblk - 1) / nblk;
   const long max_chunks = (nb + TB - 1) / TB;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
@@ -534,9 +576,15 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
         a_si = 0;
       }
       hipEvent_t stop = mgp_prof_begin(h);
-      hipLaunchKernelGGL((sweep_se_fast_kernel<DP, TileCfg<DP>::RPT>), grid, dim3(kThreads), 0, h->stream, A, na, Pk,
-                         nb, b_chunk, W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk,
-                         (int)nchunks, bmax);
+#define MGP_FAST_LAUNCH(RPTV, NTV, TB)                                                                           \
+  hipLaunchKernelGGL((sweep_se_fast_kernel<DP, RPTV, NTV, TB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, nb, b_chunk, \
+                     W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk, (int)nchunks, bmax, \
+                     h->pf_trips - 1, h->pf_ahead)
+      if (fnt == 512) MGP_FAST_LAUNCH(4, 512, 13);
+      else if (frpt == 2) MGP_FAST_LAUNCH(2, 256, 11);
+      else if (frpt == 3) MGP_FAST_LAUNCH(3, 256, 11);
+      else MGP_FAST_LAUNCH(4, 256, 11);
+#undef MGP_FAST_LAUNCH
       mgp_prof_end(h, stop);
       MGP_LAUNCH_CHECK(h);
       if (nchunks > 1) {

@@ -828,12 +828,15 @@ def test_sgpr_cg_model():
     Xs = X[:100] + 0.1
     mu, var = m.predict_f(T(Xs))
     mu0, var0 = ref.predict_f(Xs)
-    assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < 1e-5
+    # north star: 1e-6 on predictive mean AND variance.  With the model's default ("auto") preconditioner CG
+    # on S acts as iterative refinement of a factorised solve and meets it with room (measured at C1 against
+    # the longdouble oracle: 7e-11 matrix-free, 2e-8 through the explicit S; tools/dbg/sgpr_var.py)
+    assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < 1e-6
     e, e0 = m.elbo(), ref.elbo()
     assert abs(e - e0) / abs(e0) < 1e-8
     _, cov = m.predict_f(T(Xs[:20]), full_cov=True)
     _, cov0 = ref.predict_f(Xs[:20], full_cov=True)
-    assert cov.shape == (1, 20, 20) and relerr(cov, cov0) < 1e-5
+    assert cov.shape == (1, 20, 20) and relerr(cov, cov0) < 1e-6
 
 
 @pytest.mark.parametrize("pre,explicit,kmm", [(None, 0, "cg"), ("auto", 0, "cholesky"), (None, 8, "cholesky"),
@@ -850,7 +853,10 @@ def test_sgpr_solve_paths(pre, explicit, kmm):
     Xs = X[:50] + 0.05
     mu, var = m.predict_f(T(Xs))
     mu0, var0 = ref.predict_f(Xs)
-    assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < 1e-5
+    # the un-preconditioned recurrence on S (cond ~ cond(Kmm)^2) stalls at the reference's guard floor
+    #  before the variance reaches 1e-6: that is the reference algorithm's own limit, kept
+    # as a selectable path; the default path is held to the north star's 1e-6
+    assert relerr(mu, mu0) < 1e-6 and relerr(var, var0) < (1e-6 if pre == "auto" else 1e-5)
     assert (m._S is not None) == (explicit > 0)
     steps = int(m.solver().last_stats[0])
     if pre == "auto":
