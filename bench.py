@@ -36,10 +36,12 @@ SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3
 # compare: distance D fma (2D) + exp2 on a reduced argument (3 add, 2 fma, mul, fma, scale = 11) + R accumulate fma
 # (2R).  The kernel may execute fewer instructions than this (round 2 does); time is what is measured.
 ALG_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
-# VALU wave-instructions the current kernels issue per pair, by element size (csrc/sweep_fast.hip fp64 SE:
-# D + 3 + 3 + R fp64 and 3 integer; csrc/sweep.hip fp32 SE: D fma + v_exp_f32 + R fma), and the cycles one
-# wave-instruction holds a SIMD (fp64 16 lanes/clk -> 4; fp32 and 32-bit integer 32 lanes/clk -> 2)
-VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 6 + R, 3), 4: lambda D, R: (D + 1 + R, 0)}  # (float, int32)
+# VALU wave-instructions the current kernels issue per pair, by element size (csrc/sweep.hip, fp64 SE fast
+# kernel: D fma + 3 add + 2 fma + mul + fma + R fma = D + 7 + R fp64 and 2 integer -- PMC: 18.3 per pair at
+# D = 8, R = 1 with the per-point overheads; fp32 SE: D fma + v_exp_f32 + R fma), and the cycles one
+# wave-instruction holds a SIMD (fp64 16 lanes/clk -> 4; fp32 and 32-bit integer 32 lanes/clk -> 2 nominal;
+# profiles/r02_valu_issue_probe.txt: next to fp64 work an integer instruction costs ~0.75 of an fp64 slot)
+VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 7 + R, 2), 4: lambda D, R: (D + 1 + R, 0)}  # (float, int32)
 NUM_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
 CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (2, 2)}  # (float, int32) by element size
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
@@ -309,8 +311,9 @@ def main():
                               "matrix and vector peaks are the same 78.6 TFLOP/s on the same ALUs, measured and "
                               "rejected) and is not HBM-bound (SURVEY 8d) -- the hbm figures BASELINE.json asks for "
                               "are in the nested object",
-                "kernel": f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1> (K_nm.p and K_mn.u are the "
-                          "same symbol)",
+                "kernel": (f"sweep_se_fast_kernel<{D},4,512,13>" if esize == 8 and kname == "se" and D <= 8 else
+                           f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1>") +
+                          " (K_nm.p and K_mn.u are the same symbol)",
                 "achieved": ach_tflops, "peak": vector_peak, "unit": "TFLOP/s",
                 "frac": ach_tflops / vector_peak,
                 "flop_model": "algorithmic flops of the fused SE product, DESIGN.md 4.1 (2D + 11 + 2R per pair)"

@@ -292,10 +292,18 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
   if (gate != nullptr && *gate == 0) return;
   const int lin = blockIdx.x;
   int bx, by;
-  if ((nchunks & 7) == 0) {  // XCD-aware decode, as sweep_kernel
+  if ((nchunks & 7) == 0) {  // XCD-aware decode, as sweep_kernel: the workgroups that stream one chunk share an XCD
     const int grp = lin / (8 * nblk), rem = lin - grp * (8 * nblk);
     bx = rem >> 3;
     by = grp * 8 + (rem & 7);
+  } else if (nchunks <= 4) {
+    // few chunks (C3's K_nm.v: two): the workgroups that OWN the same rows -- one per chunk -- get linear ids
+    // that differ by 8, i.e. the same XCD a moment apart, so the rows are fetched from HBM once and re-read
+    // from that XCD's L2 (grid padded to a multiple of 8 row blocks; the padding exits here)
+    const int grp = lin / (8 * nchunks), rem = lin - grp * (8 * nchunks);
+    by = rem >> 3;
+    bx = grp * 8 + (rem & 7);
+    if (bx >= nblk) return;
   } else {
     by = lin / nblk;
     bx = lin - by * nblk;
@@ -520,7 +528,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   const long nblk = (na + per_block - 1) / per_block;
   // enough workgroups to fill the chip: none of the streamed set is split when the owned side
   // already gives >= 4 workgroups per CU, else aim for ~8 per CU
-  const long target = 8L * h->num_cus;
+  const long target = 8L * h->num_cus * kThreads / fnt;  // ~two resident rounds of workgroups
   // The fast kernel splits the streamed set while the owned side gives fewer than 8 (256-thread-equivalent)
   // workgroups per CU: with exactly one resident round (C3's K_nm.v: 4 per CU) the slowest CU sets the time
   // (measured 2.41 -> 2.26 ms with two chunks); the LDS-tile kernels keep the round-1 threshold
@@ -537,6 +545,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   dim3 grid((unsigned)(nblk * nchunks));
   if constexpr (std::is_same<T, double>::value && KIND == 0 && DP <= 8 && RC == 1 && !SQ) {
     if (h->sweep_fast) {
+      if ((nchunks & 7) != 0 && nchunks <= 4) grid = dim3((unsigned)((nblk + 7) / 8 * 8 * nchunks));  // see the decode
       // packed streamed set: reused across the iterations of a solve (pack_hold), else rebuilt
       mgp_handle::PackSlot* ps = nullptr;
       if (h->pack_hold)

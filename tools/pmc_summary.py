@@ -13,6 +13,10 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
         key = (row["Dispatch_Id"], row["Counter_Name"])
         per[key] += float(row["Counter_Value"])
         meta[row["Dispatch_Id"]] = (row["Kernel_Name"].split("(")[0][-60:], row.get("Grid_Size", "?"))
+    # tools/run_sweep.py alternates K_nm.v and K_mn.u; when both use the same grid, tell them apart by order
+    if "--alternate" in sys.argv:
+        order = sorted(meta, key=int)
+        meta = {d: (meta[d][0] + (" [knm]" if i % 2 == 0 else " [kmn]"), meta[d][1]) for i, d in enumerate(order)}
     for (did, cname), v in per.items():
         acc[meta[did]][cname].append(v)
 out = {}
