@@ -26,6 +26,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (pt && atoi(pt) >= 1 && (atoi(pt) & (atoi(pt) - 1)) == 0) h->pf_trips = atoi(pt);
   const char* pa = getenv("MGP_PF_AHEAD");
   if (pa && atoi(pa) >= 0) h->pf_ahead = atoi(pa);
+  const char* f32r = getenv("MGP_SWEEP_RPT32");
+  if (f32r && (atoi(f32r) == 1 || atoi(f32r) == 2)) h->sweep_fast_rpt32 = atoi(f32r);
   const char* fr = getenv("MGP_SWEEP_RPT");
   if (fr && atoi(fr) >= 2 && atoi(fr) <= 4) h->sweep_fast_rpt = atoi(fr);
   const char* pm = getenv("MGP_CONTRACT_PANEL_MB");

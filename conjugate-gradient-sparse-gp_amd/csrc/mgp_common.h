@@ -58,6 +58,7 @@ struct mgp_handle {
   // table offset; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
   int sweep_fast = 2;
   int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
+  int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
   // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
   // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)

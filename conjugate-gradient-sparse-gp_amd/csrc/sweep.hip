@@ -250,7 +250,6 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
 // Valid while the exponent stays normal: t = -|a-b|^2 >= -2(|a|^2+|b|^2) > -1000 (scaled units),
 // checked per workgroup against the packed set's maximum norm; otherwise, and for NaN inputs, the
 // clamped variant of the same loop runs (2^-1000 stands for 0; NaN stays NaN).
-constexpr double kFastLimit = 1000.0;
 
 template <int DP>
 __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restrict__ B, long nb, int D,
@@ -280,11 +279,16 @@ __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restri
 }
 
 // NT threads per workgroup share one table of 2^TBITS entries (t = m / 2^TBITS + g, |g| <= 2^-(TBITS+1)):
-//   TBITS 11, NT 256: 16 KB, four workgroups per CU; byte offset of the entry by shift + and;
+//   TBITS 11, NT 256: 16 KB, several workgroups per CU; byte offset of the entry by shift + and;
 //   TBITS 13, NT 512: 64 KB, two workgroups per CU; the offset is ONE instruction -- an SDWA shift that
-//   keeps the low 16 bits of (m << 3), i.e. (m & 8191) * 8 -- so a pair costs D + 8 fp64 + 2 integer.
-template <int DP, int RPT, int NT, int TBITS>
-__global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_se_fast_kernel(
+//   keeps the low 16 bits of (m << 3), i.e. (m & 8191) * 8 -- so an SE pair costs D + 8 fp64 + 2 integer.
+// KIND 0 (SE) folds |a|^2 into the magic constant; the Matern kinds take t = -q, q = sqrt(max(r^2, floor)),
+// through the same table and multiply by their polynomial in q (mgp_math.h, mgp_profile).
+// DBUF: two SGPR copies of the streamed row (the next point's scalar loads fly during the current point);
+// at DP = 32 a row is 66 SGPRs, so there is one copy and the next row is requested as soon as the distance
+// phase of the current point has consumed it.
+template <int DP, int KIND, int RPT, int NT, int TBITS, bool DBUF>
+__global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : (RPT == 3 ? 5 : (DP > 8 ? 4 : 8)))) void sweep_fast_kernel(
     const double* __restrict__ A, long na, const double* __restrict__ Pk, long nb, long b_chunk,
     const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_chunk, int D,
     SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, const int* __restrict__ gate,
@@ -311,8 +315,10 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
   constexpr int TSIZE = 1 << TBITS;
   constexpr double MAGIC = TBITS == 11 ? 0x1.8p+41 : 0x1.8p+39;  // ulp = 2^-TBITS: low word of t + MAGIC = round(2^TBITS t)
   static_assert(TBITS == 11 || TBITS == 13, "table sizes: 2048 or 8192 entries");
+  // the exponent must stay normal: t > -1000.  SE: t = -r^2 (scaled); Matern: t = -q, q^2 = r^2 (scaled)
+  constexpr double kTLimit = 1000.0, kNormLimit = KIND == 0 ? kTLimit : kTLimit * kTLimit;
   __shared__ double e2tab[TSIZE];
-  __shared__ double amax_w[NT / 64];
+  __shared__ unsigned long long amax_w[NT / 64];
   const int t = threadIdx.x;
   for (int e = t; e < TSIZE; e += NT) {
     unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2((double)e * (1.0 / TSIZE)));
@@ -320,8 +326,8 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
     e2tab[e] = __builtin_bit_cast(double, bits);
   }
   const long base = (long)bx * (NT * RPT);
-  double a[RPT][DP], cq[RPT], acc[RPT];
-  double amax = 0;
+  double a[RPT][DP], cq[RPT], acc[RPT];  // cq: SE -> MAGIC - |a|^2 ; Matern -> |a|^2
+  unsigned long long amax = 0;            // bit pattern of max |a|^2: orders like the value, NaN above everything
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     long i = base + q * NT + t;
@@ -333,53 +339,76 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
       a[q][d] = v;
       s = mgp_fma(v, v, s);
     }
-    amax = s > amax ? s : amax;  // a NaN norm is not taken here; it reaches the result through cq
-    cq[q] = MAGIC - s;  // rounded to a multiple of 2^-TBITS
+    const unsigned long long sb = __builtin_bit_cast(unsigned long long, s) & 0x7fffffffffffffffULL;
+    amax = sb > amax ? sb : amax;
+    cq[q] = KIND == 0 ? MAGIC - s : s;  // SE: rounded to a multiple of 2^-TBITS
     acc[q] = 0;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(amax, off, 64);
+    const unsigned long long o = __shfl_xor(amax, off, 64);
     amax = o > amax ? o : amax;
   }
   if ((t & 63) == 0) amax_w[t >> 6] = amax;
   __syncthreads();  // table + amax_w
-  double aa = 0;
+  unsigned long long ab = 0;
 #pragma unroll
-  for (int w = 0; w < NT / 64; ++w) aa = amax_w[w] > aa ? amax_w[w] : aa;
-  const double bb = __builtin_bit_cast(double, *bmax_bits);
-  const bool safe = 2.0 * (aa + bb) < kFastLimit;  // NaN compares false -> clamped loop
+  for (int w = 0; w < NT / 64; ++w) ab = amax_w[w] > ab ? amax_w[w] : ab;
+  const double aa = __builtin_bit_cast(double, ab), bb = __builtin_bit_cast(double, *bmax_bits);
+  const bool safe = 2.0 * (aa + bb) < kNormLimit;  // NaN compares false -> clamped loop
 
   const long jb = (long)by * b_chunk;
   const long je = (jb + b_chunk < nb) ? jb + b_chunk : nb;
   const double C1 = 0x1.62e42fefa39efp-1, C2 = 0x1.ebfbdff82c58fp-3, C3 = 0x1.c6b08d704a0c0p-5;  // ln2^k / k!
+  const double floor_r2 = prm.clamp;  // GPflow's 1e-36 under the sqrt, in scaled units
 
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const char* tab_bytes = (const char*)e2tab;
-  // One streamed point against the RPT owned points, in three phases so that the table gathers of all
-  // RPT pairs are in flight while the polynomial is evaluated (one LDS wait per point, not per pair).
-  auto pair_step = [&](auto clamp_tag, const double (&b)[DP], double nb2, double w) {
+  // One streamed point against the RPT owned points, in phases, so that the table gathers of all RPT pairs
+  // are in flight while the polynomial is evaluated (one LDS wait per point, not per pair).
+  // dist: the distance chains (the only consumers of the row held in SGPRs)
+  auto dist = [&](const double (&b)[DP], double nb2, double (&sv)[RPT]) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      double s = KIND == 0 ? nb2 : nb2 - cq[q];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
+      sv[q] = s;  // -(scaled r^2) (SE: + |a|^2, which the magic constant carries)
+    }
+  };
+  auto finish = [&](auto clamp_tag, const double (&sv)[RPT], double w) {
     constexpr bool CLAMP = decltype(clamp_tag)::value;
-    double g[RPT], tq[RPT];
+    double g[RPT], tq[RPT], qv[KIND == 0 ? 1 : RPT];
     unsigned ex[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-      double s = nb2;
-#pragma unroll
-      for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
-      double u = s + cq[q];
+      double u, gg;
       bool low = false;
-      if (CLAMP) {
-        const double cmin = MAGIC - kFastLimit;
-        low = u < cmin;  // false for NaN: NaN flows on
-        u = low ? cmin : u;
+      if (KIND == 0) {
+        const double s = sv[q];
+        u = s + cq[q];
+        if (CLAMP) {
+          const double cmin = MAGIC - kTLimit;
+          low = u < cmin;  // false for NaN: NaN flows on
+          u = low ? cmin : u;
+        }
+        gg = s - (u - cq[q]);
+      } else {
+        double r2 = -sv[q];
+        // the floor keeps sqrt off zero; the comparison form keeps a NaN (tf.maximum does), fmax would not --
+        // NaN inputs are caught by the norm bound and take the CLAMP variant
+        r2 = CLAMP ? (r2 < floor_r2 ? floor_r2 : r2) : __builtin_fmax(r2, floor_r2);
+        double qq = mgp_sqrt_pos(r2);
+        if (CLAMP) qq = qq > kTLimit ? kTLimit : qq;  // 2^-1000 stands for 0
+        qv[q] = qq;
+        u = MAGIC - qq;
+        gg = -qq - (u - MAGIC);
       }
       const unsigned m = __builtin_bit_cast(u32x2, u).x;  // round(2^TBITS t) in two's complement
-      const double gg = s - (u - cq[q]);
-      g[q] = CLAMP ? (low ? 0.0 : gg) : gg;
+      g[q] = (KIND == 0 && CLAMP) ? (low ? 0.0 : gg) : gg;
       // byte offset of table entry m & (2^TBITS - 1) and the exponent increment (on the high word): pinned
-      // as three 32-bit instructions (left to itself the compiler packs pairs of indices with v_perm and
-      // widens the exponent add to 64 bits: ~7 integer instructions per pair instead of 3)
+      // as 32-bit instructions (left to itself the compiler packs pairs of indices with v_perm and widens
+      // the exponent add to 64 bits: ~7 integer instructions per pair instead of 2-3)
       unsigned off;
       if (TBITS == 11)
         asm("v_lshlrev_b32 %0, 3, %1\n\tv_and_b32 %0, 0x3ff8, %0" : "=&v"(off) : "v"(m));
@@ -408,13 +437,18 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
       else
         asm("v_lshl_add_u32 %0, %1, 7, %0" : "+v"(tb.y) : "v"(ex[q]));
       const double T2 = __builtin_bit_cast(double, tb);
-      const double kv = mgp_fma(T2, pq[q], T2);
+      double kv = mgp_fma(T2, pq[q], T2);  // 2^t
+      if (KIND == 2) kv *= mgp_fma(qv[KIND == 0 ? 0 : q], MGP_LN2, 1.0);
+      if (KIND == 3) {
+        const double qq = qv[KIND == 0 ? 0 : q];
+        kv *= mgp_fma(mgp_fma(qq, MGP_LN2 * MGP_LN2 / 3.0, MGP_LN2), qq, 1.0);
+      }
       acc[q] = mgp_fma(kv, w, acc[q]);
     }
   };
   auto sweep_loop = [&](auto clamp_tag) {
-    // scalar double buffering over the chunk [jb, je): the row of the next point is requested before the
-    // current one is consumed; pointers are bumped (no 64-bit index multiplies), the count is 32-bit
+    // scalar buffering over the chunk [jb, je): rows are requested ahead of their use; pointers are bumped (no
+    // 64-bit index multiplies), the count is 32-bit
     const double* rp = Pk + jb * (DP + 1);
     const double* wp = W + jb * w_sj;
     int rem = (int)(je - jb);
@@ -425,39 +459,63 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
       const double wv = *wq;
       w = live ? wv : 0.0;
     };
-    double b0[DP], b1[DP], n0, n1, w0, w1;
-    load(rp, wp, true, b0, n0, w0);
-    // The scalar loads run only ~half a trip ahead: enough for rows that sit in L2 (Z: 300 KB), not for rows
+    // The scalar loads run only about one point ahead: enough for rows that sit in L2 (Z: 300 KB), not for rows
     // that come from HBM (the K_mn direction streams X).  So every pf_mask+1 trips each lane touches one
     // 128-byte line of the packed rows pf_ahead bytes further on (a vector load whose result is never
     // used: it only pulls the lines into this XCD's L2 before the scalar loads ask for them).
     const char* pf_end = (const char*)(Pk + (je - 1) * (DP + 1));
     int trip = 0;
     unsigned pf_sink = 0;
-    while (rem > 0) {
+    auto prefetch = [&]() {
       if ((trip++ & pf_mask) == 0) {
         // lane id recomputed here (two v_mbcnt) rather than kept live across the loop: the loop is at the
         // register limit of its occupancy
         const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const char* pa = (const char*)rp + pf_ahead + lane * 128;
         pa = pa < pf_end ? pa : pf_end;
-        // the value is looked at only when the NEXT prefetch is issued (kPfTrips trips later, long after it
+        // the value is looked at only when the NEXT prefetch is issued (many trips later, long after it
         // has landed), so the compiler's vmcnt wait for it costs nothing and the loop body never stalls on it
         asm volatile("" ::"v"(pf_sink));
         pf_sink = *(const unsigned*)pa;
       }
-      const bool m1 = rem > 1, m2 = rem > 2;
-      const double* r1 = m1 ? rp + (DP + 1) : rp;
-      const double* q1 = m1 ? wp + w_sj : wp;
-      load(r1, q1, m1, b1, n1, w1);
-      pair_step(clamp_tag, b0, n0, w0);
-      const double* r2 = m2 ? r1 + (DP + 1) : r1;
-      const double* q2 = m2 ? q1 + w_sj : q1;
-      load(r2, q2, m2, b0, n0, w0);
-      pair_step(clamp_tag, b1, n1, w1);
-      rp = r2;
-      wp = q2;
-      rem -= 2;
+    };
+    double sv[RPT];
+    if (DBUF) {
+      double b0[DP], b1[DP], n0, n1, w0, w1;
+      load(rp, wp, true, b0, n0, w0);
+      while (rem > 0) {
+        prefetch();
+        const bool m1 = rem > 1, m2 = rem > 2;
+        const double* r1 = m1 ? rp + (DP + 1) : rp;
+        const double* q1 = m1 ? wp + w_sj : wp;
+        load(r1, q1, m1, b1, n1, w1);
+        dist(b0, n0, sv);
+        finish(clamp_tag, sv, w0);
+        const double* r2 = m2 ? r1 + (DP + 1) : r1;
+        const double* q2 = m2 ? q1 + w_sj : q1;
+        load(r2, q2, m2, b0, n0, w0);
+        dist(b1, n1, sv);
+        finish(clamp_tag, sv, w1);
+        rp = r2;
+        wp = q2;
+        rem -= 2;
+      }
+    } else {
+      double b0[DP], n0, w0;
+      load(rp, wp, true, b0, n0, w0);
+      while (rem > 0) {
+        prefetch();
+        dist(b0, n0, sv);
+        const double wc = w0;
+        const bool m1 = rem > 1;
+        rp = m1 ? rp + (DP + 1) : rp;
+        wp = m1 ? wp + w_sj : wp;
+        __builtin_amdgcn_sched_barrier(0);  // the row is consumed: request the next one now, not at its use
+        load(rp, wp, m1, b0, n0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(clamp_tag, sv, wc);
+        rem -= 1;
+      }
     }
     asm volatile("" ::"v"(pf_sink));  // the last prefetch is consumed here
   };
@@ -473,10 +531,13 @@ __global__ __launch_bounds__(NT, RPT >= 4 ? 4 : (RPT == 3 ? 5 : 8)) void sweep_s
   for (int q = 0; q < RPT; ++q) {
     const long i = base + q * NT + t;
     if (i < na) {
-      double a2 = 0;
+      double v = prm.variance * acc[q];
+      if (KIND == 0) {
+        double a2 = 0;
 #pragma unroll
-      for (int d = 0; d < DP; ++d) a2 = mgp_fma(a[q][d], a[q][d], a2);
-      double v = prm.variance * acc[q] * mgp_exp2((MAGIC - cq[q]) - a2);  // 2^rho
+        for (int d = 0; d < DP; ++d) a2 = mgp_fma(a[q][d], a[q][d], a2);
+        v *= mgp_exp2((MAGIC - cq[q]) - a2);  // 2^rho: what rounding MAGIC - |a|^2 dropped
+      }
       if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si], v);
       o[i * o_si] = v;
     }
@@ -520,10 +581,13 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
                  const T* W, long w_sj, long w_sr, T* out, long o_si, long o_sr, T alpha, const T* addend,
                  long ad_si, long ad_sr, const int* gate) {
   constexpr int TB = TileCfg<DP>::TB;
-  constexpr bool kFastEligible = std::is_same<T, double>::value && KIND == 0 && DP <= 8 && RC == 1 && !SQ;
-  const int frpt = (kFastEligible && h->sweep_fast) ? h->sweep_fast_rpt : 0;  // owned points per lane, fast path
+  constexpr bool kFastEligible = std::is_same<T, double>::value && RC == 1 && !SQ;
+  // fast-path geometry: D <= 8 -> 4 owned points per lane, 512 threads, 8192-entry table (or the 256-thread form);
+  // D <= 16 -> 2 points, 512 threads; D <= 32 -> 2 points, 256 threads, 2048-entry table, one SGPR row copy
+  const bool fast_on = kFastEligible && h->sweep_fast != 0;
+  const int frpt = !fast_on ? 0 : (DP <= 8 ? h->sweep_fast_rpt : (DP > 16 ? h->sweep_fast_rpt32 : 2));  // owned points per lane
   const int RPT = frpt ? frpt : TileCfg<DP>::RPT;
-  const int fnt = (frpt && h->sweep_fast == 2) ? 512 : kThreads;  // sweep_fast 2: 512 threads share an 8192-entry table
+  const int fnt = (frpt && h->sweep_fast == 2 && DP <= 16) ? 512 : kThreads;
   const long per_block = (long)fnt * RPT;
   const long nblk = (na + per_block - 1) / per_block;
   // enough workgroups to fill the chip: none of the streamed set is split when the owned side
@@ -543,8 +607,8 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   if (nchunks > 65535) return mgp_fail(h, MGP_E_SHAPE, "sweep: too many chunks");
   if (nblk * nchunks > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "sweep: grid too large");
   dim3 grid((unsigned)(nblk * nchunks));
-  if constexpr (std::is_same<T, double>::value && KIND == 0 && DP <= 8 && RC == 1 && !SQ) {
-    if (h->sweep_fast) {
+  if constexpr (kFastEligible) {
+    if (fast_on) {
       if ((nchunks & 7) != 0 && nchunks <= 4) grid = dim3((unsigned)((nblk + 7) / 8 * 8 * nchunks));  // see the decode
       // packed streamed set: reused across the iterations of a solve (pack_hold), else rebuilt
       mgp_handle::PackSlot* ps = nullptr;
@@ -585,14 +649,22 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
         a_si = 0;
       }
       hipEvent_t stop = mgp_prof_begin(h);
-#define MGP_FAST_LAUNCH(RPTV, NTV, TB)                                                                           \
-  hipLaunchKernelGGL((sweep_se_fast_kernel<DP, RPTV, NTV, TB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, nb, b_chunk, \
-                     W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk, (int)nchunks, bmax, \
-                     h->pf_trips - 1, h->pf_ahead)
-      if (fnt == 512) MGP_FAST_LAUNCH(4, 512, 13);
-      else if (frpt == 2) MGP_FAST_LAUNCH(2, 256, 11);
-      else if (frpt == 3) MGP_FAST_LAUNCH(3, 256, 11);
-      else MGP_FAST_LAUNCH(4, 256, 11);
+#define MGP_FAST_LAUNCH(RPTV, NTV, TB, DB)                                                                       \
+  hipLaunchKernelGGL((sweep_fast_kernel<DP, KIND, RPTV, NTV, TB, DB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, nb,  \
+                     b_chunk, W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk,             \
+                     (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead)
+      if constexpr (DP <= 8) {
+        if (fnt == 512) MGP_FAST_LAUNCH(4, 512, 13, true);
+        else if (frpt == 2) MGP_FAST_LAUNCH(2, 256, 11, true);
+        else if (frpt == 3) MGP_FAST_LAUNCH(3, 256, 11, true);
+        else MGP_FAST_LAUNCH(4, 256, 11, true);
+      } else if constexpr (DP <= 16) {
+        if (fnt == 512) MGP_FAST_LAUNCH(2, 512, 13, true);
+        else MGP_FAST_LAUNCH(2, 256, 11, true);
+      } else {
+        if (frpt == 1) MGP_FAST_LAUNCH(1, 256, 11, false);
+        else MGP_FAST_LAUNCH(2, 256, 11, false);
+      }
 #undef MGP_FAST_LAUNCH
       mgp_prof_end(h, stop);
       MGP_LAUNCH_CHECK(h);
