@@ -26,6 +26,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (pt && atoi(pt) >= 1 && (atoi(pt) & (atoi(pt) - 1)) == 0) h->pf_trips = atoi(pt);
   const char* pa = getenv("MGP_PF_AHEAD");
   if (pa && atoi(pa) >= 0) h->pf_ahead = atoi(pa);
+  const char* stg = getenv("MGP_SWEEP_TARGET");
+  if (stg && atoi(stg) >= 1 && atoi(stg) <= 64) h->sweep_target_per_cu = atoi(stg);
   const char* f32r = getenv("MGP_SWEEP_RPT32");
   if (f32r && (atoi(f32r) == 1 || atoi(f32r) == 2)) h->sweep_fast_rpt32 = atoi(f32r);
   const char* fr = getenv("MGP_SWEEP_RPT");
@@ -38,6 +40,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (gk && strcmp(gk, "0") == 0) h->gemm_ksplit = 0;
   const char* sb = getenv("MGP_SKINNY_BPC");
   if (sb && atoi(sb) > 0 && atoi(sb) <= 8) h->skinny_blocks_per_cu = atoi(sb);
+  const char* sst = getenv("MGP_SKINNY_STAGGER");
+  if (sst && atoi(sst) >= 0 && atoi(sst) <= 200) h->skinny_stagger = atoi(sst);
   const char* sk = getenv("MGP_SKINNY");
   if (sk && strcmp(sk, "reg") == 0) h->skinny_mode = 0;
   const char* tm = getenv("MGP_TRI_MIN_N");

@@ -563,8 +563,13 @@ template <typename T, int NBT, int KW, bool VEC>
 __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restrict__ A, long n,
                                                               const T* __restrict__ P, long Bt,
                                                               T* __restrict__ dst, long kr_len,
-                                                              const int* __restrict__ gate) {
+                                                              const int* __restrict__ gate, int stagger) {
   if (gate != nullptr && *gate == 0) return;
+  // experiment: de-phase the workgroups (all of them otherwise request their tiles at the same instants)
+  if (stagger > 0 && stagger < 100) {
+    const int ph = (blockIdx.x + blockIdx.y) & 3;
+    for (int i = 0; i < ph * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   constexpr int EH = KW / 2;                     // k per half step
   constexpr int EPL = EH / 4;                    // consecutive k per lane and half step (4 or 8)
   constexpr int PPB = KW / 4;                    // 4-element pieces per row of P and step
@@ -638,7 +643,9 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
   int buf = 0;
   for (long kr = k_begin; kr < k_end; kr += KW, buf ^= 1) {
     const bool more = kr + KW < k_end;
-    if (more) load_step(kr + KW, an);
+    // stagger >= 100 selects ablations for diagnosis (tools/run_skinny.py): 101 = no MFMAs, 102 = no A/P loads after the first step
+    if (more && (stagger != 102 || kr == k_begin)) load_step(kr + KW, an);
+    if (stagger != 101) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       T pf[NBT];
@@ -646,6 +653,7 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
       for (int bt = 0; bt < NBT; ++bt) pf[bt] = Pl[buf * STEP + ((((wk * NBT + bt) * EPL + e) * 4 + g) * 16 + jj)];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[bt], a[e], acc[bt]);
+    }
     }
     if (more) {
       stage(buf ^ 1);
@@ -707,10 +715,10 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   dim3 grid((unsigned)jg, (unsigned)ks);
   if (vec)
     hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, true>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
-                       kr_len, gate);
+                       kr_len, gate, h->skinny_stagger);
   else
     hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, false>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
-                       kr_len, gate);
+                       kr_len, gate, h->skinny_stagger);
   MGP_LAUNCH_CHECK(h);
   if (ks > 1) {
     const long tot = Bt * n;

@@ -58,6 +58,7 @@ struct mgp_handle {
   // table offset; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
   int sweep_fast = 2;
   int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
+  int sweep_target_per_cu = 8;  // chunking of the streamed set aims at this many 256-thread workgroups per CU (MGP_SWEEP_TARGET)
   int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
   // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
@@ -69,6 +70,7 @@ struct mgp_handle {
   long tri_min_n = 1024;
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
   int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
+  int skinny_stagger = 0;  // experiment (MGP_SKINNY_STAGGER): start-up delay units between workgroup phases
   int skinny_mode = 1;  // 2 <= Bt <= 128 product: 1 = P staged through LDS, 0 = register operands (MGP_SKINNY=reg)
   int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
   // bench-only: event pairs around sweep launches (mgp_profile_enable / mgp_profile_read)

@@ -592,7 +592,7 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   const long nblk = (na + per_block - 1) / per_block;
   // enough workgroups to fill the chip: none of the streamed set is split when the owned side
   // already gives >= 4 workgroups per CU, else aim for ~8 per CU
-  const long target = 8L * h->num_cus * kThreads / fnt;  // ~two resident rounds of workgroups
+  const long target = (long)h->sweep_target_per_cu * h->num_cus * kThreads / fnt;  // workgroups to aim for (256-thread units per CU)
   // The fast kernel splits the streamed set while the owned side gives fewer than 8 (256-thread-equivalent)
   // workgroups per CU: with exactly one resident round (C3's K_nm.v: 4 per CU) the slowest CU sets the time
   // (measured 2.41 -> 2.26 ms with two chunks); the LDS-tile kernels keep the round-1 threshold

@@ -172,3 +172,22 @@ def test_product_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_integration_doc_carries_the_generated_ctypes_mirror():
+    """INTEGRATION.md's struct stubs are generated from cggp/_hip.py (tools/gen_integration_stubs.py); the
+    document may not drift from them (round 1's stale `lengthscales * 32` / missing fields)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_stubs", os.path.join(ROOT, "tools", "gen_integration_stubs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = text.index("<!-- BEGIN GENERATED: tools/gen_integration_stubs.py -->")
+    b = text.index("<!-- END GENERATED -->")
+    block = text[a:b].split("```python\n", 1)[1].rsplit("```", 1)[0]
+    assert block == mod.generate()
+    ns = {}
+    exec(block, ns)  # and it is valid Python that reproduces the layout
+    from cggp import _hip
+    for name in ("MgpKernel", "MgpOperator", "MgpPrecond", "MgpCgStats"):
+        assert ctypes.sizeof(ns[name]) == ctypes.sizeof(getattr(_hip, name))
