@@ -123,7 +123,7 @@ class TrainableCGGP:
     GEMM-regime solve run as long as the slowest (Rademacher) columns, so it is off by default."""
 
     def __init__(self, kernel, noise_variance, Z, conjugate_gradient=None, num_probes=5, *, pseudo_u, cluster_counts,
-                 num_data=None, fused_solves=False):
+                 num_data=None, fused_solves=False, independent_logdet_probes=False):
         self.kernel = kernel if isinstance(kernel, TrainableKernel) else TrainableKernel(kernel)
         self.noise_p = Parameter(noise_variance)
         self.Z = Z
@@ -134,6 +134,12 @@ class TrainableCGGP:
         self.num_data = num_data
         self.probe_seed = 0
         self.fused_solves = bool(fused_solves)
+        # True: the reference's estimator exactly -- `eval_logdet`'s backward draws its OWN Rademacher probes and
+        # runs its own probe solve (`cggp/models.py:38-41`), independent of the trace estimator's (`:310`).
+        # False (default): K^-1 Zp of the trace solve is reused -- same expectation, one CG less per step, but the
+        # two estimates are then correlated
+        self.independent_logdet_probes = bool(independent_logdet_probes)
+        self.logdet_probe_seed = 1 << 20
 
     def parameters(self):
         return self.kernel.parameters() + [self.noise_p.raw]
@@ -176,7 +182,12 @@ class TrainableCGGP:
             trace = (S * (Kmm @ probes)).sum() / probes.shape[1]  # :312-314
             reuse = True
         quad = ((Kmm @ a) * a).sum()  # :316-317
-        if reuse:
+        if reuse and self.independent_logdet_probes:
+            P = probes.shape[1]
+            own = rademacher((Kmm.shape[0], P), dt, dev, self.logdet_probe_seed)  # fresh draw, :38-39
+            self.logdet_probe_seed += 1
+            logdet = eval_logdet(KL, cg, P, own)  # second probe solve in the backward pass, :40-42
+        elif reuse:
             logdet = _LogdetFromSolution.apply(KL, S.detach(), probes)  # :319 with K^-1 Zp reused
         else:
             logdet = eval_logdet(KL, cg, self.num_probes if probes is None else probes.shape[1], probes)  # :319
@@ -285,3 +296,20 @@ def train_using_lbfgs_and_update(data, model, max_num_iters, update_fn=None, upd
     if monitor is not None and hasattr(monitor, "close"):
         monitor.close()
     return None
+
+
+def train_vanilla_using_lbfgs(data, model, clustering_fn, max_num_iters, probe_seed=0):
+    """`cggp/optimize.py:127-150`: full-batch L-BFGS over the model's trainable parameters, no inducing-point
+    update (`clustering_fn` is accepted and unused, as upstream)."""
+    return train_using_lbfgs_and_update(data, model, max_num_iters, update_fn=None, update_during_training=False,
+                                        probe_seed=probe_seed)
+
+
+def train_vanilla_using_lbfgs_and_standard_ip_update(data, model, clustering_fn, max_num_iters, probe_seed=0):
+    """`cggp/optimize.py:101-124`: as above, with `model.Z <- clustering_fn()` after every L-BFGS step (the
+    reference's own comment notes that this converges to poor minima; kept for call compatibility)."""
+    def update_fn():
+        model.Z = clustering_fn().to(model.Z.dtype)
+
+    return train_using_lbfgs_and_update(data, model, max_num_iters, update_fn=update_fn, update_during_training=True,
+                                        probe_seed=probe_seed)

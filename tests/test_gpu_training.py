@@ -162,3 +162,59 @@ def test_lbfgs_training_reduces_the_full_batch_loss():
                        num_probes=8, pseudo_u=T(u), cluster_counts=T(counts), num_data=X.shape[0])
     r2 = train_using_lbfgs_and_update((T(X), T(y)), mp, 10)
     assert r2.nit >= 1 and np.isfinite(r2.fun)
+
+
+def test_independent_logdet_probes_match_the_reference_estimator():
+    """`independent_logdet_probes=True`: the log-det gradient comes from `eval_logdet`'s own probe draw and its
+    own probe solve (`cggp/models.py:38-41`), not from the trace estimator's solution.  With the two probe sets
+    injected by hand the parameter gradient equals (value part) + (1/P) K^-1 Zq (Zq)^T contracted with dK, i.e.
+    what `eval_logdet_grad` returns for Zq; and with Zq == Zp it equals the default (reusing) path."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import rademacher
+    from cggp.training import TrainableCGGP
+    X, y, Z, u, counts = _problem("se")
+    M = Z.shape[0]
+    Zp = rademacher((M, 6), torch.float64, dev(), 0)
+
+    def grads(independent, own_seed):
+        m = TrainableCGGP(kernels.SquaredExponential(1.2, [0.9, 1.4]), 0.15, T(Z),
+                          ConjugateGradient(1e-15, max_iterations=5000), num_probes=6, pseudo_u=T(u),
+                          cluster_counts=T(counts), num_data=X.shape[0], independent_logdet_probes=independent)
+        m.logdet_probe_seed = own_seed
+        e = m.elbo((T(X[:80]), T(y[:80])), probes=Zp)
+        e.backward()
+        return float(e), torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+
+    e_reuse, g_reuse = grads(False, 0)
+    e_same, g_same = grads(True, 0)      # own draw from seed 0 == Zp: the same estimator, one more solve
+    e_other, g_other = grads(True, 12345)
+    assert e_reuse == e_same == e_other  # the value never contains the log-det (models.py:46)
+    assert float((g_same - g_reuse).abs().max()) < 1e-6 * float(g_reuse.abs().max())
+    assert float((g_other - g_reuse).abs().max()) > 1e-4 * float(g_reuse.abs().max())  # a different draw
+
+
+def test_vanilla_lbfgs_trainers():
+    """`train_vanilla_using_lbfgs` / `..._and_standard_ip_update` (optimize.py:101-150)."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import (TrainableCGGP, train_vanilla_using_lbfgs,
+                               train_vanilla_using_lbfgs_and_standard_ip_update)
+    X, y, Z, u, counts = _problem("se", N=300, M=16)
+
+    def make():
+        return TrainableCGGP(kernels.SquaredExponential(0.4, [2.5, 2.5]), 0.8, T(Z),
+                             ConjugateGradient(1e-13, max_iterations=4000), num_probes=None, pseudo_u=T(u),
+                             cluster_counts=T(counts), num_data=X.shape[0])
+    m = make()
+    l0 = float(m.training_loss((T(X), T(y))))
+    res = train_vanilla_using_lbfgs((T(X), T(y)), m, clustering_fn=None, max_num_iters=15)
+    assert float(m.training_loss((T(X), T(y)))) < l0 - 1.0 and res.nit >= 1
+    m2, calls = make(), []
+
+    def clustering_fn():
+        calls.append(1)
+        return T(Z) + 0.0  # same centres: the loss must still fall, and Z is re-assigned every step
+
+    res2 = train_vanilla_using_lbfgs_and_standard_ip_update((T(X), T(y)), m2, clustering_fn, 8)
+    assert len(calls) == res2.nit + 1 and float(m2.training_loss((T(X), T(y)))) < l0

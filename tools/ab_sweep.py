@@ -16,7 +16,7 @@ ap.add_argument("--config", default="C3")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=10)
 args = ap.parse_args()
-KEYS = ("MGP_SWEEP_FAST", "MGP_SWEEP_RPT", "MGP_PF_TRIPS", "MGP_PF_AHEAD", "MGP_SWEEP", "MGP_NOSPLIT_PER_CU", "MGP_SWEEP_RPT32", "MGP_SWEEP_TARGET")
+KEYS = ("MGP_SWEEP_FAST", "MGP_SWEEP_RPT", "MGP_PF_TRIPS", "MGP_PF_AHEAD", "MGP_SWEEP", "MGP_NOSPLIT_PER_CU", "MGP_SWEEP_RPT32", "MGP_SWEEP_TARGET", "MGP_SWEEP_WFOLD")
 N, D, M, dt, kname = synthetic.CONFIGS[args.config]
 syn = synthetic.make_inputs(N, D, M, dt)
 dev = torch.device("cuda:0")
