@@ -304,7 +304,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: CG on S=s2(Kmm+jI)+KmnKnm, K_nm matrix-free, {kname} kernel",
                        "N": N, "D": D, "M": M, "rhs": 1, "rows_per_gpu": n_local,
-                       "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M] per step"},
+                       "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M]+1 per step",
+                       "collective": ("none (one rank)" if allreduce is None else
+                                      "libmgp ncclAllReduce on the solve's stream (mgp_operator.comm)"
+                                      if getattr(allreduce, "comm", None) is not None else
+                                      "callback hook -> torch.distributed (" + args.backend + ")")},
             "roofline": {
                 "bound": "valu",
                 "bound_note": "vector-ALU issue roofline: the kernel issues no MFMA (DESIGN.md 4.1: on MI355X the fp64 "

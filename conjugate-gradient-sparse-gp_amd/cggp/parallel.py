@@ -90,7 +90,26 @@ class AllReduce:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.host_staged = dist.get_backend(group) == "gloo"
-        self.comm = None if self.host_staged else Communicator(group)
+        self.comm = None
+        self.native_error = None
+        if not self.host_staged:
+            # libmgp's own RCCL communicator.  Creating it is a collective; should it fail on ANY rank (a
+            # bootstrap problem of the node, not of the path) every rank drops to torch.distributed's RCCL
+            # through the callback hook together -- agreed by one all-reduce -- rather than hang or abort
+            try:
+                comm = Communicator(group)
+            except Exception as e:  # noqa: BLE001
+                comm, self.native_error = None, repr(e)
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if float(ok.item()) > 0.5:
+                self.comm = comm
+            else:
+                if comm is not None:
+                    comm.close()
+                import sys
+                print(f"[cggp.parallel] libmgp RCCL communicator unavailable ({self.native_error}); "
+                      "using torch.distributed all_reduce through the callback hook", file=sys.stderr)
 
     def __call__(self, t):
         if self.comm is not None:
