@@ -30,6 +30,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (stg && atoi(stg) >= 1 && atoi(stg) <= 64) h->sweep_target_per_cu = atoi(stg);
   const char* f32r = getenv("MGP_SWEEP_RPT32");
   if (f32r && (atoi(f32r) == 1 || atoi(f32r) == 2)) h->sweep_fast_rpt32 = atoi(f32r);
+  const char* frc = getenv("MGP_SWEEP_RPT_RC");
+  if (frc && (atoi(frc) == 2 || atoi(frc) == 3)) h->sweep_fast_rpt_rc = atoi(frc);
   const char* fr = getenv("MGP_SWEEP_RPT");
   if (fr && atoi(fr) >= 2 && atoi(fr) <= 4) h->sweep_fast_rpt = atoi(fr);
   const char* pm = getenv("MGP_CONTRACT_PANEL_MB");

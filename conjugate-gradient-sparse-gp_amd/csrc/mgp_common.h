@@ -60,6 +60,7 @@ struct mgp_handle {
   int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
   int sweep_target_per_cu = 8;  // chunking of the streamed set aims at this many 256-thread workgroups per CU (MGP_SWEEP_TARGET)
   int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
+  int sweep_fast_rpt_rc = 2;  // owned points per lane with 2 or 4 right-hand sides at D <= 8 (2 or 3) -- MGP_SWEEP_RPT_RC
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
   // K^T panel size per launch of the two-stage contraction: small enough to stay in the 256 MiB
   // Infinity Cache between its write (k_dense) and its ~33 re-reads (MGP_CONTRACT_PANEL_MB)

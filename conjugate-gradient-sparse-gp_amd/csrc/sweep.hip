@@ -251,14 +251,25 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
 // checked per workgroup against the packed set's maximum norm; otherwise, and for NaN inputs, the
 // clamped variant of the same loop runs (2^-1000 stands for 0; NaN stays NaN).
 
+// Rows are formed one per thread and leave through LDS, so that the block's (DP+1)*NTP doubles are written
+// as one contiguous run (a 72-byte row per lane written in place cost 220 us for 2^20 rows; this form ~50).
 template <int DP>
-__global__ __launch_bounds__(256) void pack_points_kernel(const double* __restrict__ B, long nb, int D,
-                                                          SweepParams prm, double* __restrict__ P,
-                                                          unsigned long long* __restrict__ bmax_bits) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+struct PackCfg {
+  static constexpr int NTP = DP > 16 ? 128 : 256;  // (DP+1) * NTP * 8 bytes of LDS <= 64 KB
+};
+
+template <int DP>
+__global__ __launch_bounds__(PackCfg<DP>::NTP) void pack_points_kernel(const double* __restrict__ B, long nb, int D,
+                                                                       SweepParams prm, double* __restrict__ P,
+                                                                       unsigned long long* __restrict__ bmax_bits) {
+  constexpr int NTP = PackCfg<DP>::NTP;
+  __shared__ double rows[NTP * (DP + 1)];  // odd stride in doubles: conflict-free row writes
+  const int t = threadIdx.x;
+  const long base = (long)blockIdx.x * NTP;
+  const long j = base + t;
   double s = 0;
+  double* p = rows + t * (DP + 1);
   if (j < nb) {
-    double* p = P + j * (DP + 1);
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       const double v = d < D ? B[j * D + d] * prm.inv_ls[d] : 0.0;
@@ -266,7 +277,16 @@ __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restri
       p[d] = v + v;
     }
     p[DP] = -s;
+  } else {  // row nb is the pad row (the origin): the multi-right-hand-side sweep streams an even count
+#pragma unroll
+    for (int d = 0; d <= DP; ++d) p[d] = 0.0;
   }
+  __syncthreads();
+  long live = nb + 1 - base;  // rows of this block that exist (incl. the pad row)
+  live = live > NTP ? NTP : live;
+  const int cnt = (int)live * (DP + 1);
+  double* dst = P + base * (DP + 1);
+  for (int e = t; e < cnt; e += NTP) dst[e] = rows[e];
   // max |b|^2 of the whole set (bit pattern of a non-negative double orders like the value; a NaN
   // pattern is larger than every number, so a NaN point makes the set "unsafe")
   unsigned long long bits = __builtin_bit_cast(unsigned long long, s) & 0x7fffffffffffffffULL;
@@ -275,7 +295,37 @@ __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restri
     const unsigned long long o = __shfl_xor(bits, off, 64);
     bits = o > bits ? o : bits;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(bmax_bits, bits);
+  // one atomic per block at most, and none when the word already holds as much: 16 K same-address atomics
+  // (one per wave of 2^20 rows) serialised in L2 and took 160 of this kernel's 200 us
+  __shared__ unsigned long long wmax[NTP / 64];
+  if ((t & 63) == 0) wmax[t >> 6] = bits;
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll
+    for (int w = 1; w < NTP / 64; ++w) bits = wmax[w] > bits ? wmax[w] : bits;
+    if (bits > __hip_atomic_load(bmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bmax_bits, bits);
+  }
+}
+
+// wT[j][r] = W[j * w_sj + r * w_sr]: the weights of a streamed point side by side, for the scalar loads of
+// the multi-right-hand-side fast sweep (a launch-time copy of nb * RC doubles: 0.1 % of the sweep's time)
+template <int RC>
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const double* __restrict__ W, long w_sj, long w_sr,
+                                                                long nb, double* __restrict__ wT,
+                                                                const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  __shared__ double rows[256 * (RC + 1)];
+  const int t = threadIdx.x;
+  const long base = (long)blockIdx.x * 256;
+  const long j = base + t;
+#pragma unroll
+  for (int r = 0; r < RC; ++r) rows[t * (RC + 1) + r] = j < nb ? W[j * w_sj + r * w_sr] : 0.0;  // row nb: the pad row
+  __syncthreads();
+  long live = nb + 1 - base;
+  live = live > 256 ? 256 : live;
+  const int cnt = (int)live * RC;
+  double* dst = wT + base * RC;
+  for (int e = t; e < cnt; e += 256) dst[e] = rows[(e / RC) * (RC + 1) + (e % RC)];  // RC is a power of two
 }
 
 // NT threads per workgroup share one table of 2^TBITS entries (t = m / 2^TBITS + g, |g| <= 2^-(TBITS+1)):
@@ -287,12 +337,16 @@ __global__ __launch_bounds__(256) void pack_points_kernel(const double* __restri
 // DBUF: two SGPR copies of the streamed row (the next point's scalar loads fly during the current point);
 // at DP = 32 a row is 66 SGPRs, so there is one copy and the next row is requested as soon as the distance
 // phase of the current point has consumed it.
-template <int DP, int KIND, int RPT, int NT, int TBITS, bool DBUF>
-__global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : (RPT == 3 ? 5 : (DP > 8 ? 4 : 8)))) void sweep_fast_kernel(
+// RC right-hand sides: the weights of a streamed point are RC consecutive doubles (w_sj = RC: the caller hands
+// the transposed copy made by transpose_weights_kernel), read by one scalar load into RC SGPR pairs; each
+// pair's kernel value feeds RC accumulators.
+template <int DP, int KIND, int RC, int RPT, int NT, int TBITS, bool DBUF>
+__global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT == 512 || DP > 8 ? 4 : (RPT == 3 ? 5 : 8))) void sweep_fast_kernel(
     const double* __restrict__ A, long na, const double* __restrict__ Pk, long nb, long b_chunk,
-    const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_chunk, int D,
-    SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, const int* __restrict__ gate,
-    int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits, int pf_mask, int pf_ahead) {
+    const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_sr, long o_chunk, int D,
+    SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, long ad_sr,
+    const int* __restrict__ gate, int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits,
+    int pf_mask, int pf_ahead) {
   if (gate != nullptr && *gate == 0) return;
   const int lin = blockIdx.x;
   int bx, by;
@@ -326,7 +380,7 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
     e2tab[e] = __builtin_bit_cast(double, bits);
   }
   const long base = (long)bx * (NT * RPT);
-  double a[RPT][DP], cq[RPT], acc[RPT];  // cq: SE -> MAGIC - |a|^2 ; Matern -> |a|^2
+  double a[RPT][DP], cq[RPT], acc[RPT][RC];  // cq: SE -> MAGIC - |a|^2 ; Matern -> |a|^2
   unsigned long long amax = 0;            // bit pattern of max |a|^2: orders like the value, NaN above everything
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -342,7 +396,8 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
     const unsigned long long sb = __builtin_bit_cast(unsigned long long, s) & 0x7fffffffffffffffULL;
     amax = sb > amax ? sb : amax;
     cq[q] = KIND == 0 ? MAGIC - s : s;  // SE: rounded to a multiple of 2^-TBITS
-    acc[q] = 0;
+#pragma unroll
+    for (int r = 0; r < RC; ++r) acc[q][r] = 0;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -376,10 +431,11 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
       sv[q] = s;  // -(scaled r^2) (SE: + |a|^2, which the magic constant carries)
     }
   };
-  auto finish = [&](auto clamp_tag, const double (&sv)[RPT], double w) {
+  auto finish = [&](auto clamp_tag, const double (&sv)[RPT], const double (&w)[RC]) {
     constexpr bool CLAMP = decltype(clamp_tag)::value;
     double g[RPT], tq[RPT], qv[KIND == 0 ? 1 : RPT];
     unsigned ex[RPT];
+    bool under[RPT];  // CLAMP only: t below the limit -> the pair contributes an exact 0, as exp's underflow does
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       double u, gg;
@@ -399,11 +455,15 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
         // NaN inputs are caught by the norm bound and take the CLAMP variant
         r2 = CLAMP ? (r2 < floor_r2 ? floor_r2 : r2) : __builtin_fmax(r2, floor_r2);
         double qq = mgp_sqrt_pos(r2);
-        if (CLAMP) qq = qq > kTLimit ? kTLimit : qq;  // 2^-1000 stands for 0
+        if (CLAMP) {
+          low = qq > kTLimit;
+          qq = low ? kTLimit : qq;
+        }
         qv[q] = qq;
         u = MAGIC - qq;
         gg = -qq - (u - MAGIC);
       }
+      under[q] = low;
       const unsigned m = __builtin_bit_cast(u32x2, u).x;  // round(2^TBITS t) in two's complement
       g[q] = (KIND == 0 && CLAMP) ? (low ? 0.0 : gg) : gg;
       // byte offset of table entry m & (2^TBITS - 1) and the exponent increment (on the high word): pinned
@@ -443,56 +503,127 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
         const double qq = qv[KIND == 0 ? 0 : q];
         kv *= mgp_fma(mgp_fma(qq, MGP_LN2 * MGP_LN2 / 3.0, MGP_LN2), qq, 1.0);
       }
-      acc[q] = mgp_fma(kv, w, acc[q]);
+      if (CLAMP) kv = under[q] ? 0.0 : kv;
+#pragma unroll
+      for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
     }
   };
   auto sweep_loop = [&](auto clamp_tag) {
     // scalar buffering over the chunk [jb, je): rows are requested ahead of their use; pointers are bumped (no
     // 64-bit index multiplies), the count is 32-bit
+    const long wst = RC > 1 ? (long)RC : w_sj;  // RC > 1: the transposed copy, RC doubles per point
     const double* rp = Pk + jb * (DP + 1);
-    const double* wp = W + jb * w_sj;
+    const double* wp = W + jb * wst;
     int rem = (int)(je - jb);
-    auto load = [&](const double* r, const double* wq, bool live, double (&b)[DP], double& nb2, double& w) {
+    auto load = [&](const double* r, const double* wq, bool live, double (&b)[DP], double& nb2, double (&w)[RC]) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) b[d] = r[d];
       nb2 = r[DP];
-      const double wv = *wq;
-      w = live ? wv : 0.0;
+#pragma unroll
+      for (int c = 0; c < RC; ++c) {
+        const double wv = wq[c];
+        w[c] = live ? wv : 0.0;
+      }
     };
     // The scalar loads run only about one point ahead: enough for rows that sit in L2 (Z: 300 KB), not for rows
     // that come from HBM (the K_mn direction streams X).  So every pf_mask+1 trips each lane touches one
     // 128-byte line of the packed rows pf_ahead bytes further on (a vector load whose result is never
     // used: it only pulls the lines into this XCD's L2 before the scalar loads ask for them).
     const char* pf_end = (const char*)(Pk + (je - 1) * (DP + 1));
+    // RC > 1: the transposed weights stream like the rows; both buffers are the library's own and end in
+    // pf_ahead + 8 KB of slack, so the prefetch address needs no clamp there (SGPRs are short)
     int trip = 0;
-    unsigned pf_sink = 0;
+    unsigned pf_sink = 0, pw_sink = 0;
     auto prefetch = [&]() {
-      if ((trip++ & pf_mask) == 0) {
+      // RC > 1: a countdown (SGPRs are short there; the mask form re-read pf_mask from the kernel arguments
+      // every trip and waited for every scalar load in flight)
+      bool now;
+      if (RC > 1) {
+        now = trip == 0;
+        trip = now ? pf_mask : trip - 1;
+      } else {
+        now = (trip++ & pf_mask) == 0;
+      }
+      if (now) {
         // lane id recomputed here (two v_mbcnt) rather than kept live across the loop: the loop is at the
         // register limit of its occupancy
         const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const char* pa = (const char*)rp + pf_ahead + lane * 128;
-        pa = pa < pf_end ? pa : pf_end;
+        if (RC == 1) pa = pa < pf_end ? pa : pf_end;
         // the value is looked at only when the NEXT prefetch is issued (many trips later, long after it
         // has landed), so the compiler's vmcnt wait for it costs nothing and the loop body never stalls on it
         asm volatile("" ::"v"(pf_sink));
         pf_sink = *(const unsigned*)pa;
+        if (RC > 1) {
+          const char* pb = (const char*)wp + pf_ahead + lane * 128;
+          asm volatile("" ::"v"(pw_sink));
+          pw_sink = *(const unsigned*)pb;
+        }
       }
     };
     double sv[RPT];
-    if (DBUF) {
-      double b0[DP], b1[DP], n0, n1, w0, w1;
+    if constexpr (RC > 1) {
+      // Several right-hand sides: ONE copy of the weights, requested when its point's distance phase starts
+      // and used when that point's finish ends (the wait for the table gathers in between covers it) -- a
+      // second copy a point ahead, as the rows have, does not fit the SGPR file next to them.
+      auto load_row = [&](const double* r, double (&b)[DP], double& nb2) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) b[d] = r[d];
+        nb2 = r[DP];
+      };
+      auto load_w = [&](const double* wq, double (&w)[RC]) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) w[c] = wq[c];
+      };
+      double w0[RC];
+      if (DBUF) {  // an even count (pad row with zero weights): no tail mask
+        double b0[DP], b1[DP], n0, n1;
+        load_row(rp, b0, n0);
+        while (rem > 0) {
+          prefetch();
+          const double* r1 = rp + (DP + 1);
+          load_row(r1, b1, n1);
+          load_w(wp, w0);
+          dist(b0, n0, sv);
+          finish(clamp_tag, sv, w0);
+          const double* r2 = rem > 2 ? r1 + (DP + 1) : r1;
+          load_row(r2, b0, n0);
+          load_w(wp + RC, w0);
+          dist(b1, n1, sv);
+          finish(clamp_tag, sv, w0);
+          rp = r2;
+          wp += 2 * RC;
+          rem -= 2;
+        }
+      } else {
+        double b0[DP], n0;
+        load_row(rp, b0, n0);
+        while (rem > 0) {
+          prefetch();
+          load_w(wp, w0);
+          dist(b0, n0, sv);
+          rp = rem > 1 ? rp + (DP + 1) : rp;
+          __builtin_amdgcn_sched_barrier(0);  // the row is consumed: request the next one now, not at its use
+          load_row(rp, b0, n0);
+          __builtin_amdgcn_sched_barrier(0);
+          finish(clamp_tag, sv, w0);
+          wp += RC;
+          rem -= 1;
+        }
+      }
+    } else if (DBUF) {
+      double b0[DP], b1[DP], n0, n1, w0[RC], w1[RC];
       load(rp, wp, true, b0, n0, w0);
       while (rem > 0) {
         prefetch();
         const bool m1 = rem > 1, m2 = rem > 2;
         const double* r1 = m1 ? rp + (DP + 1) : rp;
-        const double* q1 = m1 ? wp + w_sj : wp;
+        const double* q1 = m1 ? wp + wst : wp;
         load(r1, q1, m1, b1, n1, w1);
         dist(b0, n0, sv);
         finish(clamp_tag, sv, w0);
         const double* r2 = m2 ? r1 + (DP + 1) : r1;
-        const double* q2 = m2 ? q1 + w_sj : q1;
+        const double* q2 = m2 ? q1 + wst : q1;
         load(r2, q2, m2, b0, n0, w0);
         dist(b1, n1, sv);
         finish(clamp_tag, sv, w1);
@@ -501,15 +632,17 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
         rem -= 2;
       }
     } else {
-      double b0[DP], n0, w0;
+      double b0[DP], n0, w0[RC];
       load(rp, wp, true, b0, n0, w0);
       while (rem > 0) {
         prefetch();
         dist(b0, n0, sv);
-        const double wc = w0;
+        double wc[RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) wc[c] = w0[c];
         const bool m1 = rem > 1;
         rp = m1 ? rp + (DP + 1) : rp;
-        wp = m1 ? wp + w_sj : wp;
+        wp = m1 ? wp + wst : wp;
         __builtin_amdgcn_sched_barrier(0);  // the row is consumed: request the next one now, not at its use
         load(rp, wp, m1, b0, n0, w0);
         __builtin_amdgcn_sched_barrier(0);
@@ -518,6 +651,7 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
       }
     }
     asm volatile("" ::"v"(pf_sink));  // the last prefetch is consumed here
+    if (RC > 1) asm volatile("" ::"v"(pw_sink));
   };
   if (jb < je) {
     if (safe)
@@ -531,15 +665,20 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 ? 4 : 
   for (int q = 0; q < RPT; ++q) {
     const long i = base + q * NT + t;
     if (i < na) {
-      double v = prm.variance * acc[q];
+      double rho = 1.0;
       if (KIND == 0) {
         double a2 = 0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) a2 = mgp_fma(a[q][d], a[q][d], a2);
-        v *= mgp_exp2((MAGIC - cq[q]) - a2);  // 2^rho: what rounding MAGIC - |a|^2 dropped
+        rho = mgp_exp2((MAGIC - cq[q]) - a2);  // 2^rho: what rounding MAGIC - |a|^2 dropped
       }
-      if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si], v);
-      o[i * o_si] = v;
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        double v = prm.variance * acc[q][r];
+        if (KIND == 0) v *= rho;
+        if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si + r * ad_sr], v);
+        o[i * o_si + r * o_sr] = v;
+      }
     }
   }
 }
@@ -581,11 +720,12 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
                  const T* W, long w_sj, long w_sr, T* out, long o_si, long o_sr, T alpha, const T* addend,
                  long ad_si, long ad_sr, const int* gate) {
   constexpr int TB = TileCfg<DP>::TB;
-  constexpr bool kFastEligible = std::is_same<T, double>::value && RC == 1 && !SQ;
+  constexpr bool kFastEligible = std::is_same<T, double>::value && !SQ;
   // fast-path geometry: D <= 8 -> 4 owned points per lane, 512 threads, 8192-entry table (or the 256-thread form);
   // D <= 16 -> 2 points, 512 threads; D <= 32 -> 2 points, 256 threads, 2048-entry table, one SGPR row copy
-  const bool fast_on = kFastEligible && h->sweep_fast != 0;
-  const int frpt = !fast_on ? 0 : (DP <= 8 ? h->sweep_fast_rpt : (DP > 16 ? h->sweep_fast_rpt32 : 2));  // owned points per lane
+  // several right-hand sides: 2 owned points per lane (the RC accumulators per point take the registers), 512-thread form only
+  const bool fast_on = kFastEligible && h->sweep_fast != 0 && (RC == 1 || h->sweep_fast == 2);
+  const int frpt = !fast_on ? 0 : (RC > 1 ? (DP > 16 ? 1 : ((RC <= 4 && DP <= 8) ? h->sweep_fast_rpt_rc : 2)) : (DP <= 8 ? h->sweep_fast_rpt : (DP > 16 ? h->sweep_fast_rpt32 : 2)));  // owned points per lane
   const int RPT = frpt ? frpt : TileCfg<DP>::RPT;
   const int fnt = (frpt && h->sweep_fast == 2 && DP <= 16) ? 512 : kThreads;
   const long per_block = (long)fnt * RPT;
@@ -621,9 +761,11 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
         ps = &h->pack[h->pack_next];
         h->pack_next ^= 1;
         ps->valid = false;
-        MGP_TRY(mgp_reserve(h, &ps->buf, &ps->bytes, 64 + (size_t)nb * (DP + 1) * sizeof(double)));
+        MGP_TRY(mgp_reserve(h, &ps->buf, &ps->bytes,
+                            64 + (size_t)(nb + 1) * (DP + 1) * sizeof(double) + h->pf_ahead + 8192));
         MGP_HIP(h, hipMemsetAsync(ps->buf, 0, 64, h->stream));
-        hipLaunchKernelGGL((pack_points_kernel<DP>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, B,
+        constexpr int NTP = PackCfg<DP>::NTP;
+        hipLaunchKernelGGL((pack_points_kernel<DP>), dim3((unsigned)((nb + NTP) / NTP)), dim3(NTP), 0, h->stream, B,
                            nb, D, prm, (double*)((char*)ps->buf + 64), (unsigned long long*)ps->buf);
         MGP_LAUNCH_CHECK(h);
         ps->src = (const void*)B;
@@ -634,26 +776,48 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
       }
       const double* Pk = (const double*)((char*)ps->buf + 64);
       const unsigned long long* bmax = (const unsigned long long*)ps->buf;
+      if constexpr (RC > 1) {
+        MGP_TRY(mgp_reserve(h, &h->gen, &h->gen_bytes, (size_t)(nb + 1) * RC * sizeof(double) + h->pf_ahead + 8192));
+        hipLaunchKernelGGL((transpose_weights_kernel<RC>), dim3((unsigned)((nb + 256) / 256)), dim3(256), 0,
+                           h->stream, W, w_sj, w_sr, nb, (double*)h->gen, gate);
+        MGP_LAUNCH_CHECK(h);
+        W = (const T*)h->gen;
+        w_sj = RC;
+        nb += nb & 1;  // an even count: the two-points-per-trip loop needs no tail mask (pad row, zero weights)
+      }
       T* dst = out;
-      long d_si = o_si, d_chunk = 0;
+      long d_si = o_si, d_sr = o_sr, d_chunk = 0;
       T a_alpha = alpha;
       const T* a_add = addend;
-      long a_si = ad_si;
-      if (nchunks > 1) {
-        MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nchunks * na * sizeof(T)));
+      long a_si = ad_si, a_sr = ad_sr;
+      if (nchunks > 1) {  // partials [chunk][r][i], as reduce_partials_kernel reads them
+        MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nchunks * na * RC * sizeof(T)));
         dst = (T*)h->ws;
         d_si = 1;
-        d_chunk = na;
+        d_sr = na;
+        d_chunk = na * (long)RC;
         a_alpha = 0;
         a_add = nullptr;
-        a_si = 0;
+        a_si = a_sr = 0;
       }
       hipEvent_t stop = mgp_prof_begin(h);
 #define MGP_FAST_LAUNCH(RPTV, NTV, TB, DB)                                                                       \
-  hipLaunchKernelGGL((sweep_fast_kernel<DP, KIND, RPTV, NTV, TB, DB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, nb,  \
-                     b_chunk, W, w_sj, dst, d_si, d_chunk, D, prm, a_alpha, a_add, a_si, gate, (int)nblk,             \
-                     (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead)
-      if constexpr (DP <= 8) {
+  hipLaunchKernelGGL((sweep_fast_kernel<DP, KIND, RC, RPTV, NTV, TB, DB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, \
+                     nb, b_chunk, W, w_sj, dst, d_si, d_sr, d_chunk, D, prm, a_alpha, a_add, a_si, a_sr, gate,        \
+                     (int)nblk, (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead)
+      if constexpr (RC > 1) {
+        // two SGPR copies of (row, weights) while they fit: (DP + 1 + RC) doubles each
+        if constexpr (DP > 16) {
+          MGP_FAST_LAUNCH(1, 256, 11, false);  // one owned point per lane: 64 VGPRs of coordinates + 2 RC of sums
+        } else if constexpr (DP <= 8 && RC <= 4) {
+          if (frpt == 3) MGP_FAST_LAUNCH(3, 512, 13, true);
+          else MGP_FAST_LAUNCH(2, 512, 13, true);
+        } else if constexpr (DP + 1 + RC <= 17) {
+          MGP_FAST_LAUNCH(2, 512, 13, true);
+        } else {
+          MGP_FAST_LAUNCH(2, 512, 13, false);
+        }
+      } else if constexpr (DP <= 8) {
         if (fnt == 512) MGP_FAST_LAUNCH(4, 512, 13, true);
         else if (frpt == 2) MGP_FAST_LAUNCH(2, 256, 11, true);
         else if (frpt == 3) MGP_FAST_LAUNCH(3, 256, 11, true);
@@ -669,8 +833,9 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
       mgp_prof_end(h, stop);
       MGP_LAUNCH_CHECK(h);
       if (nchunks > 1) {
-        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((na + 63) / 64)), dim3(1024), 0, h->stream,
-                           (const T*)h->ws, na, 1, (int)nchunks, out, o_si, o_sr, alpha, addend, ad_si, ad_sr, gate);
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((na * RC + 63) / 64)), dim3(1024), 0,
+                           h->stream, (const T*)h->ws, na, RC, (int)nchunks, out, o_si, o_sr, alpha, addend, ad_si,
+                           ad_sr, gate);
         MGP_LAUNCH_CHECK(h);
       }
       return MGP_OK;

@@ -87,7 +87,7 @@ if "sweeps" in which:
         syn = synthetic.make_inputs(N, D, M, dt, need_y=False)
         X, Z = torch.from_numpy(syn.X).to(dev), torch.from_numpy(syn.Z).to(dev)
         k = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname](1.0, [1.0] * D)
-        for R in (1, 4, 8):
+        for R in (1, 2, 4, 8):
             V = torch.randn(M, R, dtype=X.dtype, device=dev)
             W = torch.randn(N, R, dtype=X.dtype, device=dev)
             ms = timeit(lambda: ops.knm_matvec(k.spec(D), X, Z, V))
