@@ -46,6 +46,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (sst && atoi(sst) >= 0 && atoi(sst) <= 200) h->skinny_stagger = atoi(sst);
   const char* sk = getenv("MGP_SKINNY");
   if (sk && strcmp(sk, "reg") == 0) h->skinny_mode = 0;
+  const char* skp = getenv("MGP_SKINNY_PIPE");
+  if (skp && strcmp(skp, "0") == 0) h->skinny_pipe = 0;
   const char* tm = getenv("MGP_TRI_MIN_N");
   if (tm && atol(tm) > 0) h->tri_min_n = atol(tm);
   const char* ns = getenv("MGP_NOSPLIT_PER_CU");

@@ -8,6 +8,7 @@
 // pass over A and does the Bt-wide contraction on the matrix cores (symm_skinny_kernel); larger
 // Bt is an LDS-tiled NT GEMM on v_mfma_f64_16x16x4_f64 (v_mfma_f32_16x16x4_f32 for fp32), which
 // also serves the K_mn K_nm contraction (contract.hip) and the generic-D products (generic.hip).
+#include <algorithm>
 #include <cstdlib>
 
 #include "mgp_common.h"
@@ -559,7 +560,9 @@ __global__ __launch_bounds__(512) void symm_skinny_kernel(const T* __restrict__ 
 // register-prefetched one step ahead.  Slices of the contraction index (grid.y) write their own
 // [Bt,n] partial, summed in slice order by skinny_reduce_kernel -- deterministic.  P is read in its
 // original [Bt,n] layout (no transpose pass).
-template <typename T, int NBT, int KW, bool VEC>
+constexpr int TLW = 128;  // timeline words per workgroup (ABL 5/6)
+
+template <typename T, int NBT, int KW, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restrict__ A, long n,
                                                               const T* __restrict__ P, long Bt,
                                                               T* __restrict__ dst, long kr_len,
@@ -588,7 +591,6 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
   const T* arow = A + j * n;
   const long k_begin = (long)blockIdx.y * kr_len;
   const long k_end = k_begin + kr_len < n ? k_begin + kr_len : n;
-  dst += (long)blockIdx.y * Bt * n;
   Acc acc[NBT];
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
@@ -635,32 +637,52 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
       }
     }
   };
+  // ABL 5: timeline of each workgroup (thread 0: s_memtime at entry, after the prologue, after every step's
+  // barrier, at exit; s_memrealtime at entry and exit) into the 48 words per workgroup that the launch reserved
+  // behind the partials
+  unsigned long long* tl = nullptr;
+  int tli = 0;
+  if ((ABL == 5 || ABL == 6)) {
+    tl = (unsigned long long*)(dst + (long)gridDim.y * Bt * n) + (long)(blockIdx.y * gridDim.x + blockIdx.x) * TLW;
+    if (t == 0) {
+      tl[0] = __builtin_amdgcn_s_memrealtime();
+      tl[1] = __builtin_amdgcn_s_memtime();
+    }
+    tli = 2;
+  }
+  dst += (long)blockIdx.y * Bt * n;
   if (k_begin < k_end) {
     load_step(k_begin, a);
     stage(0);
   }
   __syncthreads();
+  if ((ABL == 5 || ABL == 6) && t == 0) tl[tli++] = __builtin_amdgcn_s_memtime();
   int buf = 0;
   for (long kr = k_begin; kr < k_end; kr += KW, buf ^= 1) {
     const bool more = kr + KW < k_end;
-    // stagger >= 100 selects ablations for diagnosis (tools/run_skinny.py): 101 = no MFMAs, 102 = no A/P loads after the first step
-    if (more && (stagger != 102 || kr == k_begin)) load_step(kr + KW, an);
-    if (stagger != 101) {
+    // ABL selects ablations for diagnosis (tools/run_skinny.py, MGP_SKINNY_STAGGER=101..104): 1 = no MFMAs,
+    // 2 = no A/P loads after the first step, 3 = 2 + no barrier, 4 = 3 + no LDS operand reads
+    if (more && (ABL < 2 || (ABL == 5 || ABL == 6) || kr == k_begin)) load_step(kr + KW, an);
+    if (ABL == 6 && t == 0) tl[tli++] = __builtin_amdgcn_s_memtime();  // loads issued
+    if (ABL != 1) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       T pf[NBT];
 #pragma unroll
-      for (int bt = 0; bt < NBT; ++bt) pf[bt] = Pl[buf * STEP + ((((wk * NBT + bt) * EPL + e) * 4 + g) * 16 + jj)];
+      for (int bt = 0; bt < NBT; ++bt) pf[bt] = ABL == 4 ? a[(e + bt) % EPL] : Pl[buf * STEP + ((((wk * NBT + bt) * EPL + e) * 4 + g) * 16 + jj)];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[bt], a[e], acc[bt]);
     }
     }
+    if (ABL == 6 && t == 0) tl[tli++] = __builtin_amdgcn_s_memtime();  // MFMAs issued
     if (more) {
       stage(buf ^ 1);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) a[e] = an[e];
     }
-    __syncthreads();
+    if (ABL == 6 && t == 0) tl[tli++] = __builtin_amdgcn_s_memtime();  // loads landed, next panel staged
+    if (ABL < 3 || (ABL == 5 || ABL == 6)) __syncthreads();
+    if ((ABL == 5 || ABL == 6) && t == 0 && tli < TLW - 4) tl[tli++] = __builtin_amdgcn_s_memtime();
   }
   // the two k halves of a row tile meet in LDS (upper half stores, lower half adds and writes)
   T* red = Pl;
@@ -680,6 +702,178 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
         const long b = bt * 16 + Mfma<T>::row(lane, r);
         if (b < Bt && jo < n) dst[b * n + jo] = acc[bt][r] + red[((wj * NBT + bt) * 4 + r) * 64 + lane];
       }
+  }
+  if ((ABL == 5 || ABL == 6) && t == 0) {
+    tl[tli++] = __builtin_amdgcn_s_memtime();
+    tl[TLW - 2] = (unsigned long long)tli;
+    tl[TLW - 1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// The same product, software-pipelined (n a multiple of 64, NBT <= 4).  The timeline of the kernel above
+// (MGP_SKINNY_STAGGER=106, profiles/r02_skinny_timeline.txt) showed where its step went: all 8 loads of a thread
+// were issued in one burst at the top of the step -- 64 KB per CU, 1024+ cycles of the CU's 64 B/clk vector
+// memory path, during which the in-order waves could not issue MFMAs (1500 cycles) -- and came back 5000
+// cycles later, after the step's MFMAs had drained (2300 cycles at s_waitcnt vmcnt).  Here
+//   * the A fragments are requested TWO steps ahead (HBM under load: ~2.5 us), the P panel one step ahead (L2);
+//   * one 32-byte load is issued after every second group of 4 MFMAs instead of 8 in a burst;
+//   * no bounds branches in the loop: rows of P beyond Bt and rows of A beyond n are clamped to the last valid
+//     row (their results are never written), and n % 64 == 0 keeps every k step whole;
+//   * operand fragments of MFMA group e+1 are read from LDS before group e is issued (explicitly: the
+//     scheduling barriers that fix the load positions also stop the compiler from doing it).
+// Same lane/element mapping and the same order of accumulation as the kernel above: bit-identical results.
+template <typename T, int NBT, int ABL = 0>
+__global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restrict__ A, long n,
+                                                               const T* __restrict__ P, long Bt,
+                                                               T* __restrict__ dst, long kr_len,
+                                                               const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int KW = 64, EH = 32, EPL = 8, PPB = 16;
+  constexpr int STEP = NBT * 16 * KW;
+  constexpr int NPIECE = NBT * 16 * PPB;
+  constexpr int NV = (NPIECE + 511) / 512;
+  constexpr int REDN = NBT * 1024;
+  constexpr int LDSN = 2 * STEP > REDN ? 2 * STEP : REDN;
+  constexpr int NU = 2 + NV;  // 32-byte load units per thread and step: 2 of A, NV of P
+  using Acc = typename Mfma<T>::Acc;
+  using V4 = __attribute__((ext_vector_type(4))) T;
+  __shared__ __attribute__((aligned(32))) T Pl[LDSN];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wj = wave & 3, wk = wave >> 2;
+  const int jj = lane & 15, g = lane >> 4;
+  const long j0 = (long)blockIdx.x * 64 + wj * 16;
+  const long j = j0 + jj < n ? j0 + jj : n - 1;
+  const long k_begin = (long)blockIdx.y * kr_len;
+  const long k_end = k_begin + kr_len < n ? k_begin + kr_len : n;
+  const int nsteps = (int)((k_end - k_begin) / KW);
+  unsigned long long* tl = nullptr;
+  int tli = 0;
+  if (ABL == 5) {
+    tl = (unsigned long long*)(dst + (long)gridDim.y * Bt * n) + (long)(blockIdx.y * gridDim.x + blockIdx.x) * TLW;
+    if (t == 0) {
+      tl[0] = __builtin_amdgcn_s_memrealtime();
+      tl[1] = __builtin_amdgcn_s_memtime();
+    }
+    tli = 2;
+  }
+  dst += (long)blockIdx.y * Bt * n;
+  // per-thread source pointers at k_begin; a step advances them by KW elements
+  const T* ap = A + j * n + k_begin + wk * EH + EPL * g;
+  const T* pp[NV];
+  int pdst[NV];  // LDS element offset of the piece's first element within a staging buffer
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    // no predicate anywhere on the staging path (a load whose only use sits in a conditional block is sunk into
+    // it by the compiler, next to its use, and its whole latency is exposed): with fewer pieces than threads
+    // the surplus threads stage a twin's piece again -- the same values to the same words
+    const int vv = (t + 512 * i) % NPIECE;
+    const int kq = (vv >> 4) % PPB, bt = (vv >> 4) / PPB;
+    long b = bt * 16 + (vv & 15);
+    b = b < Bt ? b : Bt - 1;
+    pp[i] = P + b * n + k_begin + 4 * kq;
+    const int kh = kq / (EH / 4), kk0 = 4 * (kq % (EH / 4));
+    const int gg = kk0 / EPL, e0 = kk0 % EPL;
+    pdst[i] = (((kh * NBT + bt) * EPL + e0) * 4 + gg) * 16 + (vv & 15);
+  }
+  Acc acc[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
+  V4 a0[2], a1[2], a2[2], ps[NV];
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Pl[buf * STEP + pdst[i] + e * 64] = ps[i][e];
+    }
+  };
+  if (nsteps > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ps[i] = *reinterpret_cast<const V4*>(pp[i]);
+    a0[0] = *reinterpret_cast<const V4*>(ap);
+    a0[1] = *reinterpret_cast<const V4*>(ap + 4);
+    const long o1 = nsteps > 1 ? KW : 0;
+    a1[0] = *reinterpret_cast<const V4*>(ap + o1);
+    a1[1] = *reinterpret_cast<const V4*>(ap + o1 + 4);
+    stage(0);
+  }
+  __syncthreads();
+  if (ABL == 5 && t == 0) tl[tli++] = __builtin_amdgcn_s_memtime();
+  const T* lds_rd = Pl + (wk * NBT * EPL * 4 + g) * 16 + jj;  // + (bt * EPL + e) * 64 per operand
+  // one k step: MFMAs on `ac` (the A fragments of step s) against LDS buffer s & 1; requests the P panel of step
+  // s+1 (staged at the end of this step) and the A fragments of step s+2 into `ain` (clamped to the last step:
+  // the few repeated requests at the end hit in cache).  The three fragment sets rotate by NAME over a loop
+  // unrolled by three -- a register copy of a set still in flight would wait for it.
+  // The step's barrier sits BEFORE its last MFMA group: that group's operands are read ahead of the barrier,
+  // the first group of the next step is read right after it, and the four MFMAs in between cover the LDS latency
+  // (a barrier after the last MFMA left the matrix pipe idle for staging + barrier + read latency, ~700 of a
+  // step's 4800 cycles).  The panel of the next step is staged after group 5, by when its loads (requested after
+  // groups 0 and 2) have landed.
+  T pf[2][NBT];
+  auto do_step = [&](int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+    const int buf = s & 1;
+    const long op = (long)(s + 1 < nsteps ? s + 1 : nsteps - 1) * KW;
+    const long oa = (long)(s + 2 < nsteps ? s + 2 : nsteps - 1) * KW;
+    auto issue = [&](int u) {
+      if (u < NV) {
+        ps[u] = *reinterpret_cast<const V4*>(pp[u] + op);
+      } else if (u < NU) {
+        ain[u - NV] = *reinterpret_cast<const V4*>(ap + oa + 4 * (u - NV));
+      }
+    };
+    const T* rd = lds_rd + buf * STEP;
+#pragma unroll
+    for (int e = 0; e < EPL - 1; ++e) {
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) pf[(e + 1) & 1][bt] = rd[(bt * EPL + e + 1) * 64];
+      const T av = ac[e >> 2][e & 3];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[e & 1][bt], av, acc[bt]);
+      // NU <= 4 units over 8 groups: one after every second group (the last groups stay free of requests)
+      if ((e & 1) == 0) issue(e >> 1);
+      if (e == 5) stage(buf ^ 1);  // unconditional (see above); after the last step that buffer is not read again
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (ABL == 5 && t == 0 && tli < TLW - 4) tl[tli++] = __builtin_amdgcn_s_memtime();
+    const T* rn = lds_rd + (buf ^ 1) * STEP;
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) pf[0][bt] = rn[(bt * EPL) * 64];
+    {
+      const T av = ac[1][3];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[1][bt], av, acc[bt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) pf[0][bt] = lds_rd[(bt * EPL) * 64];  // group 0 of step 0 (buffer 0)
+  for (int s = 0; s < nsteps; s += 3) {
+    do_step(s, a0, a2);
+    if (s + 1 < nsteps) do_step(s + 1, a1, a0);
+    if (s + 2 < nsteps) do_step(s + 2, a2, a1);
+  }
+  T* red = Pl;
+  if (wk == 1) {
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wj * NBT + bt) * 4 + r) * 64 + lane] = acc[bt][r];
+  }
+  __syncthreads();
+  if (wk == 0) {
+    const long jo = j0 + jj;
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long b = bt * 16 + Mfma<T>::row(lane, r);
+        if (b < Bt && jo < n) dst[b * n + jo] = acc[bt][r] + red[((wj * NBT + bt) * 4 + r) * 64 + lane];
+      }
+  }
+  if (ABL == 5 && t == 0) {
+    tl[tli++] = __builtin_amdgcn_s_memtime();
+    tl[TLW - 2] = (unsigned long long)tli;
+    tl[TLW - 1] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -708,18 +902,80 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   ks = (n + kr_len - 1) / kr_len;
   T* dst = out;
   if (ks > 1) {
-    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)ks * Bt * n * sizeof(T)));
+    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)ks * Bt * n * sizeof(T) + (size_t)jg * ks * TLW * 8));
     dst = (T*)h->ws;
   }
   const bool vec = (n % 4) == 0 && (((uintptr_t)A) % 32) == 0 && (((uintptr_t)P) % 32) == 0;
   dim3 grid((unsigned)jg, (unsigned)ks);
-  if (vec)
+  bool piped = false;
+  if constexpr (NBT == 2 || NBT == 4) {  // Bt <= 16 is bound by the A stream and the round-1 form already runs at it (29.7 vs 34.2 us)
+    if (vec && (n % 64) == 0 && h->skinny_pipe && (h->skinny_stagger <= 100 || h->skinny_stagger == 107)) {
+      piped = true;
+      if (h->skinny_stagger == 107)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, 5>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst, kr_len,
+                           gate);
+      else
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst, kr_len,
+                           gate);
+    }
+  }
+  if (piped) {
+  } else if (vec && h->skinny_stagger > 100 && NBT == 4 && std::is_same<T, double>::value) {  // diagnosis only
+#define MGP_SK_ABL(V)                                                                                              \
+  hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, true, V>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst, \
+                     kr_len, gate, 0)
+    if (h->skinny_stagger == 101) MGP_SK_ABL(1);
+    else if (h->skinny_stagger == 102) MGP_SK_ABL(2);
+    else if (h->skinny_stagger == 103) MGP_SK_ABL(3);
+    else if (h->skinny_stagger == 104) MGP_SK_ABL(4);
+    else if (ks > 1) {
+      if (h->skinny_stagger == 105) MGP_SK_ABL(5);
+      else MGP_SK_ABL(6);
+    }
+#undef MGP_SK_ABL
+  } else if (vec)
     hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, true>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
                        kr_len, gate, h->skinny_stagger);
   else
     hipLaunchKernelGGL((symm_skinny_lds_kernel<T, NBT, KW, false>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst,
                        kr_len, gate, h->skinny_stagger);
   MGP_LAUNCH_CHECK(h);
+  if (h->skinny_stagger >= 105 && h->skinny_stagger <= 107 && ks > 1 && NBT == 4) {
+    {
+      static int dumps = 0;
+      if (dumps++ == 4) {  // the fifth call (warm): per-phase s_memtime deltas, median / max over workgroups
+        MGP_HIP(h, hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> tl((size_t)jg * ks * TLW);
+        MGP_HIP(h, hipMemcpy(tl.data(), (const char*)dst + (size_t)ks * Bt * n * sizeof(T), tl.size() * 8,
+                             hipMemcpyDeviceToHost));
+        const size_t nw = (size_t)jg * ks;
+        unsigned long long r0 = ~0ULL, r1 = 0;
+        for (size_t w = 0; w < nw; ++w) {
+          r0 = tl[w * TLW] < r0 ? tl[w * TLW] : r0;
+          r1 = tl[w * TLW + TLW - 1] > r1 ? tl[w * TLW + TLW - 1] : r1;
+        }
+        fprintf(stderr, "skinny timeline: %zu workgroups, first entry -> last exit %.2f us (s_memrealtime, 100 MHz)\n", nw,
+                (double)(r1 - r0) / 100.0);
+        const int cnt = (int)tl[TLW - 2];
+        for (int i = 1; i < cnt; ++i) {
+          std::vector<double> d;
+          for (size_t w = 0; w < nw; ++w) d.push_back((double)(tl[w * TLW + i] - tl[w * TLW + (i == 1 ? 0 : i - 1)]));
+          std::sort(d.begin(), d.end());
+          if (i == 1) continue;
+          fprintf(stderr, "  phase %2d: median %8.0f  min %8.0f  max %8.0f ticks\n", i - 2, d[nw / 2], d[0], d[nw - 1]);
+        }
+        std::vector<double> e, x;
+        for (size_t w = 0; w < nw; ++w) {
+          e.push_back((double)(tl[w * TLW] - r0) / 100.0);
+          x.push_back((double)(tl[w * TLW + TLW - 1] - tl[w * TLW]) / 100.0);
+        }
+        std::sort(e.begin(), e.end());
+        std::sort(x.begin(), x.end());
+        fprintf(stderr, "  entry offset us: median %.2f max %.2f; workgroup lifetime us: median %.2f min %.2f max %.2f\n",
+                e[nw / 2], e[nw - 1], x[nw / 2], x[0], x[nw - 1]);
+      }
+    }
+  }
   if (ks > 1) {
     const long tot = Bt * n;
     hipLaunchKernelGGL((skinny_reduce_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,

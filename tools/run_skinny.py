@@ -9,6 +9,10 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 A = torch.randn(n, n, dtype=torch.float64, device=dev, generator=g); A = A + A.t()
 P = torch.randn(Bt, n, dtype=torch.float64, device=dev, generator=g)
+if os.environ.get("SKINNY_DATA") == "zeros":  # power experiment: the same instruction stream on all-zero operands
+    A.zero_(); P.zero_()
+elif os.environ.get("SKINNY_DATA") == "ones":
+    A.fill_(1.0); P.fill_(1.0)
 for _ in range(3):
     out = ops.symm_matmul(A, P)
 torch.cuda.synchronize()
