@@ -268,6 +268,30 @@ def test_symm_matmul_fp64(n, Bt):
     assert out.shape == (Bt, n) and relerr(out, P @ A) < 1e-12
 
 
+@pytest.mark.parametrize("n", [64, 128, 1280, 2048, 3072, 4608])
+@pytest.mark.parametrize("Bt", [17, 32, 33, 48, 64])
+def test_symm_matmul_pipelined_form(n, Bt, monkeypatch):
+    """n % 64 == 0 and 16 < Bt <= 64 take the software-pipelined kernel (step counts 1, 2, 4, 8, 18 per slice:
+    every remainder of its loop unrolled by three; Bt not a multiple of 16 exercises the clamped panel rows).
+    Checked against numpy and, bit for bit, against the round-1 form run on a second handle."""
+    import ctypes
+    from cggp import _hip, ops
+    rng = np.random.default_rng(n + Bt)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    P = rng.standard_normal((Bt, n))
+    At, Pt = T(A), T(P)
+    out = ops.symm_matmul(At, Pt)
+    assert relerr(out, P @ A) < 1e-12
+    monkeypatch.setenv("MGP_SKINNY_PIPE", "0")
+    hd = _hip.Handle(At.device.index or 0)
+    hd.sync_stream()
+    ref = torch.empty_like(Pt)
+    hd.check(hd.lib.mgp_symm_matmul(hd.h, _hip.dtype_code(At), _hip.ptr(At), n, _hip.ptr(Pt), Bt, _hip.ptr(ref)))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("Bt", [1, 8, 33, 200])
 def test_symm_matmul_fp32(Bt):
     from cggp import ops
