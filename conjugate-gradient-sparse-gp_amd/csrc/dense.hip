@@ -344,6 +344,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
     }
   };
   load_tiles(0);
+  if constexpr (VEC && WT == 4) {
+    // Throughput shape, whole 16-element k steps: the next step's operand loads carry no predicate (rows beyond
+    // m / n are clamped to row 0 and their results never written; the step after the last re-reads the last) and
+    // go out in four pairs, one behind each group of 16 MFMAs -- not as a burst of eight in front of them, during
+    // which the in-order wave issues no MFMA (the skinny product's timeline).
+    constexpr int VW = 16 / sizeof(T);
+    constexpr int NL = EPT / VW;  // 16-byte loads per operand, thread and step
+    using V = __attribute__((ext_vector_type(VW))) T;
+    V np[NL], na_[NL];  // staged at the top of the next step straight from these registers: no copy of a load in flight
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+#pragma unroll
+      for (int x = 0; x < VW; ++x) {
+        np[u][x] = pre_p[u * VW + x];
+        na_[u][x] = pre_a[u * VW + x];
+      }
+    for (long k0 = 0; k0 < K; k0 += BK) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+#pragma unroll
+        for (int x = 0; x < VW; ++x) {
+          Ps[srow * LDS_S + skk + u * VW + x] = np[u][x];
+          As[srow * LDS_S + skk + u * VW + x] = na_[u][x];
+        }
+      __syncthreads();
+      const long kn = (k0 + BK < K ? k0 + BK : k0) + skk;
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 4) {
+        T af[WT], bf[WT];
+#pragma unroll
+        for (int mi = 0; mi < WT; ++mi)
+          af[mi] = Ps[(wm * 16 * WT + mi * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+#pragma unroll
+        for (int q = 0; q < WT; ++q) bf[q] = As[(wn * 16 * WT + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
+#pragma unroll
+        for (int mi = 0; mi < WT; ++mi)
+#pragma unroll
+          for (int q = 0; q < WT; ++q) acc[mi][q] = Mfma<T>::run(af[mi], bf[q], acc[mi][q]);
+        constexpr int G = (NL + 3) / 4;  // loads per operand behind this group
+#pragma unroll
+        for (int u = (ks / 4) * G; u < (ks / 4 + 1) * G && u < NL; ++u) {
+          np[u] = *reinterpret_cast<const V*>(prow + kn + u * VW);
+          na_[u] = *reinterpret_cast<const V*>(arow + kn + u * VW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else
   for (long k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
