@@ -67,6 +67,40 @@ def test_fullsize_kernel_products(cfg):
     assert torch.equal(t, ops.kmn_matvec(spec, X, Z, w))
 
 
+@pytest.mark.parametrize("cfg,R", [("C3", 8), ("C3r", 2), ("C3", 4), ("C5", 4), ("C5", 8)])
+def test_fullsize_products_several_right_hand_sides(cfg, R):
+    """The multi-right-hand-side sweeps (transposed weights, RC accumulators per pair) at config size: spot
+    rows / columns of every column against the oracle, each column against the one-column kernel, odd N
+    (C3r: the pad row of the even-count loop), run-to-run determinism."""
+    from cggp import ops
+    syn, X, Z, kern, ko, tdt = setup(cfg)
+    N, D = syn.X.shape
+    M = syn.Z.shape[0]
+    spec = kern.spec(D)
+    rng = np.random.default_rng(40 + R)
+    V = torch.from_numpy(rng.standard_normal((M, R))).to(dev())
+    W = torch.from_numpy(rng.standard_normal((N, R))).to(dev())
+    U = ops.knm_matvec(spec, X, Z, V)
+    Tt = ops.kmn_matvec(spec, X, Z, W)
+    assert U.shape == (N, R) and Tt.shape == (M, R) and torch.isfinite(U).all() and torch.isfinite(Tt).all()
+    rows = np.r_[0, 1, N - 1, N - 2, rng.integers(0, N, 28)]
+    ref = ko.K(syn.X[rows], syn.Z) @ V.cpu().numpy()
+    assert np.max(np.abs(U.cpu().numpy()[rows] - ref)) / np.max(np.abs(ref)) < 1e-11
+    cols = np.r_[0, M - 1, rng.integers(0, M, 4)]
+    ref_t = np.zeros((len(cols), R))
+    Wn = W.cpu().numpy()
+    for s0 in range(0, N, 65536):
+        ref_t += ko.K(syn.Z[cols], syn.X[s0:s0 + 65536]) @ Wn[s0:s0 + 65536]
+    assert np.max(np.abs(Tt.cpu().numpy()[cols] - ref_t)) / np.max(np.abs(ref_t)) < 1e-11
+    # a column of the batched product against the one-column kernel (different kernels, same sums up to rounding)
+    for r in (0, R - 1):
+        u1 = ops.knm_matvec(spec, X, Z, V[:, r:r + 1].contiguous())
+        t1 = ops.kmn_matvec(spec, X, Z, W[:, r:r + 1].contiguous())
+        assert float((U[:, r:r + 1] - u1).abs().max()) / float(u1.abs().max()) < 1e-12
+        assert float((Tt[:, r:r + 1] - t1).abs().max()) / float(t1.abs().max()) < 1e-12
+    assert torch.equal(Tt, ops.kmn_matvec(spec, X, Z, W)) and torch.equal(U, ops.knm_matvec(spec, X, Z, V))
+
+
 def test_fullsize_sgpr_operator_properties():
     from cggp import ops, synthetic
     from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
