@@ -43,7 +43,10 @@ ALG_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
 # profiles/r02_valu_issue_probe.txt: next to fp64 work an integer instruction costs ~0.75 of an fp64 slot)
 VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 7 + R, 2), 4: lambda D, R: (D + 1 + R, 0)}  # (float, int32)
 NUM_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
-CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (2, 2)}  # (float, int32) by element size
+# fp32: the sweep's scalar (non-packed) v_fma_f32 / v_exp_f32 hold the SIMD 4 cycles per wave (16 lanes/clk; the
+# 157 TFLOP/s datasheet peak needs v_pk_fma_f32) -- PMC on C4, profiles/r02_pmc_c4_sweep.json: SQ_INSTS_VALU x 4
+# cycles = 0.90 of the kernel's cycles
+CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (4, 4)}  # (float, int32) by element size
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
 
 

@@ -71,6 +71,12 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
 
   // SE / fp64 fast path: a2 is folded into the exp2 magic constant (mgp_exp2_tab_shifted)
   constexpr bool FAST = KIND == 0 && sizeof(T) == 8 && !SQ;
+  // SE / fp32: while every owned point of the workgroup has |a|^2 < 64 (log2 units; fp32 reaches 2^127, and the sums carry up to nb terms times |w| on top of 2^64)
+  // the sums are kept scaled by 2^(|a_i|^2): the pair's exponent is 2 a.b - |b|^2 <= |a|^2 -- no overflow, and it
+  // underflows only where the kernel value does -- so the subtraction of |a|^2 leaves the loop (4 instead of 5
+  // instructions per pair at D = 2) and returns as one factor 2^(-|a_i|^2) per output.  Same rounding behaviour:
+  // the expansion form already carries terms of size |a|^2 + |b|^2 in the exponent.
+  constexpr bool FOLD32 = KIND == 0 && sizeof(T) == 4 && !SQ;
 
   // ---- owned points: scaled coordinates and squared norm in registers
   // (FAST keeps only cq per owned point live across the sweep; a2 and the 2^rho scales are
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
       bb = bmax_w[w] > bb ? bmax_w[w] : bb;
     }
     const bool safe = (T)2 * (aa + bb) < (T)524288;  // NaN inputs compare false -> clamped loop
+    const bool fold = FOLD32 && aa < (T)64;          // the same for every tile of this workgroup (aa: owned points only)
 
     auto body = [&](auto e2) {
 #pragma unroll UJ
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
           for (int d = 0; d < DP; ++d) s = mgp_fma(a[q][d], b[d], s);
           T kv = mgp_profile<KIND, T, decltype(e2)>(s, clamp, e2);
           if (SQ) kv = kv * kv;
+          if (FOLD32) kv = fold ? kv * mgp_exp2(a2q) : kv;  // rare path of a folding workgroup: match the scale of its sums
           if (FAST) kv = (T)((double)kv * mgp_exp2(-(((double)MGP_EXP2_MAGIC - cq[FAST ? q : 0]) - (double)a2q)));
 #pragma unroll
           for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
@@ -206,9 +214,33 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
         }
       }
     };
+    auto body_fold = [&]() {
+#pragma unroll UJ
+      for (int jj = 0; jj < TB; ++jj) {
+        const T* p = &tile[jj * PS];
+        T b[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) b[d] = p[d];
+        const T nb2 = p[DP];
+        T w[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          T sx = nb2;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) sx = mgp_fma(a[q][d], b[d], sx);
+          const T kv = mgp_exp2(sx);
+#pragma unroll
+          for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
+        }
+      }
+    };
     if (safe) {
       if (FAST)
         body_fast();
+      else if (FOLD32 && fold)
+        body_fold();
       else
         body(E2Tab<false>{e2tab});
     } else {
@@ -217,6 +249,13 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
   }
 
   const T var = SQ ? (T)(prm.variance * prm.variance) : (T)prm.variance;
+  bool folded = false;
+  if (FOLD32 && jb < je) {  // the loop ran, so amax_w is published (its barrier precedes the first tile)
+    T aa = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) aa = amax_w[w] > aa ? amax_w[w] : aa;
+    folded = aa < (T)64;
+  }
   T* o = out + (long)by * o_chunk;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -226,6 +265,7 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
       for (int r = 0; r < RC; ++r) {
         T v = var * acc[q][r];
         if (FAST) v = (T)((double)v * mgp_exp2(((double)MGP_EXP2_MAGIC - cq[q]) - (double)norm2(q)));  // 2^rho
+        if (FOLD32) v = folded ? v * mgp_exp2(-a2[FAST ? 0 : q]) : v;
         if (addend != nullptr) v = mgp_fma(alpha, addend[i * ad_si + r * ad_sr], v);
         o[i * o_si + r * o_sr] = v;
       }
