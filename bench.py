@@ -41,12 +41,13 @@ ALG_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
 # D = 8, R = 1 with the per-point overheads; fp32 SE: D fma + v_exp_f32 + R fma), and the cycles one
 # wave-instruction holds a SIMD (fp64 16 lanes/clk -> 4; fp32 and 32-bit integer 32 lanes/clk -> 2 nominal;
 # profiles/r02_valu_issue_probe.txt: next to fp64 work an integer instruction costs ~0.75 of an fp64 slot)
-VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 7 + R, 2), 4: lambda D, R: (D + 1 + R, 0)}  # (float, int32)
+# fp32 (C4): D + R fp32 fma slots (v_fma_f32 holds a SIMD 2 cycles per wave, v_pk_fma_f32 4 cycles for two pairs) and one
+# v_exp_f32, which holds it 8 cycles -- tools/micro/valu_issue.hip, profiles/r02_valu_issue_probe_fp32.txt: 16 fma32
+# 9.8 ms, 16 pk_fma32 18.1 ms, 16 exp32 34.7 ms against 16 fma64 18.6 ms; mixes add up, nothing overlaps.  The second
+# entry of each pair is "the other kind": 32-bit integer instructions for fp64, the transcendental for fp32.
+VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 7 + R, 2), 4: lambda D, R: (D + R, 1)}  # (float, other)
 NUM_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
-# fp32: the sweep's scalar (non-packed) v_fma_f32 / v_exp_f32 hold the SIMD 4 cycles per wave (16 lanes/clk; the
-# 157 TFLOP/s datasheet peak needs v_pk_fma_f32) -- PMC on C4, profiles/r02_pmc_c4_sweep.json: SQ_INSTS_VALU x 4
-# cycles = 0.90 of the kernel's cycles
-CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (4, 4)}  # (float, int32) by element size
+CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (2, 8)}  # (float, other) by element size
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
 
 
@@ -326,7 +327,7 @@ def main():
                 "flop_model": "algorithmic flops of the fused SE product, DESIGN.md 4.1 (2D + 11 + 2R per pair)"
                               if flop_model_exact else "the SE count applied to another kernel: approximate",
                 "flop_per_pair": ALG_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
-                "valu_instr_per_pair": {"float": n_fl, "int32": n_int},
+                "valu_instr_per_pair": {"float": n_fl, ("int32" if esize == 8 else "transcendental"): n_int},
                 "valu_issue_frac_at_2.4GHz": issue_s / (sweep_ms * 1e-3),
                 "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
                 "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12

@@ -225,14 +225,34 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
         T w[RC];
 #pragma unroll
         for (int r = 0; r < RC; ++r) w[r] = p[DP + 1 + r];
+        if constexpr (sizeof(T) == 4) {
+          // two owned points per instruction: v_pk_fma_f32 for the distance chains and the accumulation (the
+          // streamed operand is the same value in both halves), v_exp_f32 once per pair
+          typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-          T sx = nb2;
+          for (int q = 0; q < RPT; q += 2) {
+            v2f sx = {nb2, nb2};
 #pragma unroll
-          for (int d = 0; d < DP; ++d) sx = mgp_fma(a[q][d], b[d], sx);
-          const T kv = mgp_exp2(sx);
+            for (int d = 0; d < DP; ++d)
+              sx = __builtin_elementwise_fma(v2f{a[q][d], a[q + 1][d]}, v2f{b[d], b[d]}, sx);
+            const v2f kv = {mgp_exp2(sx.x), mgp_exp2(sx.y)};
 #pragma unroll
-          for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
+            for (int r = 0; r < RC; ++r) {
+              const v2f ac = __builtin_elementwise_fma(kv, v2f{w[r], w[r]}, v2f{acc[q][r], acc[q + 1][r]});
+              acc[q][r] = ac.x;
+              acc[q + 1][r] = ac.y;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < RPT; ++q) {
+            T sx = nb2;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) sx = mgp_fma(a[q][d], b[d], sx);
+            const T kv = mgp_exp2(sx);
+#pragma unroll
+            for (int r = 0; r < RC; ++r) acc[q][r] = mgp_fma(kv, w[r], acc[q][r]);
+          }
         }
       }
     };

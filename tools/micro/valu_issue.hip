@@ -22,13 +22,18 @@ enum Mix {
   FMA64_16_DSB128,     // 16 v_fma_f64 + 1 ds_read_b128 (uniform address)
   FMA64_16_DSGATHER4,  // 16 v_fma_f64 + 4 ds_read_b64 (per-lane pseudo-random address)
   FMA64_16_DSGATHER4_NC,  // same, conflict-free addresses (lane*8)
+  PKFMA32_16,          // 16 v_pk_fma_f32
+  EXP32_16,            // 16 v_exp_f32
+  PKFMA32_12_EXP4,     // 12 v_pk_fma_f32 + 4 v_exp_f32 (does the transcendental overlap packed math?)
+  RSQ64_4_FMA12,       // 4 v_rsq_f64 + 12 v_fma_f64
   NMIX
 };
 static const char* kNames[NMIX] = {"16 fma64", "16 add64", "16 mul64", "16 fma64 + 4 and32", "16 fma64 + 8 and32",
                                    "16 fma64 + 4 lshl_add", "16 fma64 + 4 ldexp64", "12 fma64 + 4 ldexp64",
                                    "16 and32", "16 fma32", "16 fma64 (sgpr operand)", "16 fma64 + 1 ds_read_b128 bcast",
-                                   "16 fma64 + 4 ds_read_b64 gather (random)", "16 fma64 + 4 ds_read_b64 (conflict-free)"};
-static const int kInstr[NMIX] = {16, 16, 16, 20, 24, 20, 20, 16, 16, 16, 16, 17, 20, 20};
+                                   "16 fma64 + 4 ds_read_b64 gather (random)", "16 fma64 + 4 ds_read_b64 (conflict-free)",
+                                   "16 pk_fma32", "16 exp32", "12 pk_fma32 + 4 exp32", "4 rsq64 + 12 fma64"};
+static const int kInstr[NMIX] = {16, 16, 16, 20, 24, 20, 20, 16, 16, 16, 16, 17, 20, 20, 16, 16, 16, 16};
 
 #define F64(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b))
 #define REP16(M) M(0); M(1); M(2); M(3); M(4); M(5); M(6); M(7); M(8); M(9); M(10); M(11); M(12); M(13); M(14); M(15)
@@ -93,6 +98,23 @@ __global__ __launch_bounds__(256) void probe(double* out, long long* cyc, int it
     if (MIX == FMA32_16) {
 #define F32(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(z[i]) : "v"(af), "v"(bf))
       REP16(F32);
+    }
+    if (MIX == PKFMA32_16) {
+#define PK32(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b))
+      REP16(PK32);
+    }
+    if (MIX == EXP32_16) {
+#define EX32(i) asm volatile("v_exp_f32 %0, %0" : "+v"(z[i]))
+      REP16(EX32);
+    }
+    if (MIX == PKFMA32_12_EXP4) {
+      REP12(PK32);
+      EX32(12); EX32(13); EX32(14); EX32(15);
+    }
+    if (MIX == RSQ64_4_FMA12) {
+      REP12(F64);
+#define RSQ(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(x[i]))
+      RSQ(12); RSQ(13); RSQ(14); RSQ(15);
     }
     if (MIX == FMA64_16_SGPR) {
 #define F64S(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "s"(as))
@@ -200,5 +222,9 @@ int main() {
   run_all<FMA64_16_DSB128>();
   run_all<FMA64_16_DSGATHER4>();
   run_all<FMA64_16_DSGATHER4_NC>();
+  run_all<PKFMA32_16>();
+  run_all<EXP32_16>();
+  run_all<PKFMA32_12_EXP4>();
+  run_all<RSQ64_4_FMA12>();
   return 0;
 }
