@@ -113,6 +113,22 @@ def test_sweep_ragged_shapes(N, M):
     assert relerr(ops.kmn_matvec(k.spec(D), T(X), T(Z), T(W)), K.T @ W) < 1e-11
 
 
+@pytest.mark.parametrize("N,M", [(1, 1), (5, 1), (1, 5), (255, 257), (4097, 513)])
+@pytest.mark.parametrize("R", [2, 8])
+@pytest.mark.parametrize("name,D", [("se", 8), ("matern52", 16), ("matern32", 32)])
+def test_sweep_ragged_shapes_several_right_hand_sides(N, M, R, name, D):
+    """The multi-right-hand-side fast sweeps stream an even count (pad row with zero weights) and read the
+    weights from a transposed copy: odd / tiny streamed sets in both directions, every RC instantiation."""
+    from cggp import ops
+    k, ko = make_kernel(name, D)
+    X, Z = points(N, M, D)
+    rng = np.random.default_rng(N + M + R)
+    V, W = rng.standard_normal((M, R)), rng.standard_normal((N, R))
+    K = ko.K(X, Z)
+    assert relerr(ops.knm_matvec(k.spec(D), T(X), T(Z), T(V)), K @ V) < 1e-11
+    assert relerr(ops.kmn_matvec(k.spec(D), T(X), T(Z), T(W)), K.T @ W) < 1e-11
+
+
 def test_sweep_empty_inputs():
     from cggp import ops
     D = 3
