@@ -157,6 +157,42 @@ def test_sweep_fp32(name):
     assert relerr(a, K @ V) < 2e-4 and relerr(b, K.T @ W) < 2e-4
 
 
+@pytest.mark.parametrize("D,R", [(2, 1), (2, 3), (5, 2), (8, 1)])
+def test_sweep_fp32_se_scaled_sums(D, R):
+    """fp32 SE keeps the sums scaled by 2^|a|^2 while every owned point of a workgroup has |a|^2 < 64: workgroups
+    that qualify, workgroups that do not (a block of owned points far from the origin), far streamed points (the
+    general loop inside a scaled workgroup), and coincident points -- rows compared one by one so that a wrong
+    scale on a few rows cannot hide in a norm."""
+    from cggp import kernels, ops
+    N, M = 5000, 700
+    k = kernels.SquaredExponential(variance=1.3, lengthscales=[0.7] * D)
+    ko = ok.Kernel("se", 1.3, np.full(D, 0.7))
+    X, Z = points(N, M, D)
+    X[1024:2048] += 9.0      # |a|^2 ~ D * 120 in log2 units: these row blocks do not scale their sums
+    X[3000:3010] = 400.0     # far streamed points for the K_mn direction: the distance bound of their tile fails
+    X[:50] = Z[:50]          # coincident points
+    Z[600:] += 9.0
+    rng = np.random.default_rng(11)
+    V, W = rng.standard_normal((M, R)), rng.standard_normal((N, R))
+    K = ko.K(X, Z)
+    f = torch.float32
+    a = ops.knm_matvec(k.spec(D), T(X, f), T(Z, f), T(V, f)).double().cpu().numpy()
+    b = ops.kmn_matvec(k.spec(D), T(X, f), T(Z, f), T(W, f)).double().cpu().numpy()
+    ra, rb = K @ V, K.T @ W
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    # Row-wise bound of the fp32 expansion form itself (GPflow's in fp32 just as much): the exponent of pair (i,j)
+    # is formed from terms of size |a_i|^2 + |b_j|^2 (log2 units), so term j of row i is off by about
+    # eps32 * (1 + |a_i|^2 + |b_j|^2) * |w_j| k_ij.  A wrong scale factor on a row would miss this bound by orders.
+    eps = float(np.finfo(np.float32).eps)
+    c2 = 0.5 * np.log2(np.e) / 0.7 ** 2
+    na2, nb2 = c2 * (X * X).sum(1), c2 * (Z * Z).sum(1)
+    G = K * (1.0 + na2[:, None] + nb2[None, :])
+    bound_a = 8 * eps * (G @ np.abs(V)) + 1e-30
+    bound_b = 8 * eps * (G.T @ np.abs(W)) + 1e-30
+    assert np.max(np.abs(a - ra) / bound_a) < 1.0
+    assert np.max(np.abs(b - rb) / bound_b) < 1.0
+
+
 def test_sweep_coincident_points_and_far_points():
     from cggp import ops
     D = 8
