@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
   }
 }
 
-// The same product, software-pipelined (n a multiple of 64, NBT <= 4).  The timeline of the kernel above
+// The same product, software-pipelined (any n >= 256, NBT = 2 or 4).  The timeline of the kernel above
 // (MGP_SKINNY_STAGGER=106, profiles/r02_skinny_timeline.txt) showed where its step went: all 8 loads of a thread
 // were issued in one burst at the top of the step -- 64 KB per CU, 1024+ cycles of the CU's 64 B/clk vector
 // memory path, during which the in-order waves could not issue MFMAs (1500 cycles) -- and came back 5000
@@ -767,11 +767,13 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
 //   * the A fragments are requested TWO steps ahead (HBM under load: ~2.5 us), the P panel one step ahead (L2);
 //   * one 32-byte load is issued after every second group of 4 MFMAs instead of 8 in a burst;
 //   * no bounds branches in the loop: rows of P beyond Bt and rows of A beyond n are clamped to the last valid
-//     row (their results are never written), and n % 64 == 0 keeps every k step whole;
+//     row (their results are never written); a partial last k step (n % 64 != 0) is requested element by element
+//     with zeros past n, by a second instantiation of the step that only the last three steps of the last slice run;
+//     rows are read with element-aligned 32-byte vector loads, so n need not be a multiple of 4;
 //   * operand fragments of MFMA group e+1 are read from LDS before group e is issued (explicitly: the
 //     scheduling barriers that fix the load positions also stop the compiler from doing it).
 // Same lane/element mapping and the same order of accumulation as the kernel above: bit-identical results.
-template <typename T, int NBT, int ABL = 0>
+template <typename T, int NBT, bool AL, bool RAG, int ABL = 0>
 __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restrict__ A, long n,
                                                                const T* __restrict__ P, long Bt,
                                                                T* __restrict__ dst, long kr_len,
@@ -785,7 +787,10 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   constexpr int LDSN = 2 * STEP > REDN ? 2 * STEP : REDN;
   constexpr int NU = 2 + NV;  // 32-byte load units per thread and step: 2 of A, NV of P
   using Acc = typename Mfma<T>::Acc;
-  using V4 = __attribute__((ext_vector_type(4))) T;
+  typedef T V4r __attribute__((ext_vector_type(4)));
+  // AL: n % 4 == 0 and 32-byte aligned bases -> naturally aligned 32-byte loads; otherwise rows start at arbitrary
+  // multiples of the element size and the loads carry element alignment only
+  typedef V4r V4 __attribute__((aligned(AL ? 4 * sizeof(T) : sizeof(T))));
   __shared__ __attribute__((aligned(32))) T Pl[LDSN];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wj = wave & 3, wk = wave >> 2;
@@ -794,7 +799,11 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   const long j = j0 + jj < n ? j0 + jj : n - 1;
   const long k_begin = (long)blockIdx.y * kr_len;
   const long k_end = k_begin + kr_len < n ? k_begin + kr_len : n;
-  const int nsteps = (int)((k_end - k_begin) / KW);
+  const int nsteps = (int)((k_end - k_begin + KW - 1) / KW);
+  // n % 64 != 0: the last step of the last slice is partial.  Its operands are loaded element by element with
+  // zeros past n (both of them), by the steps that request it; every other step keeps the vector loads.
+  // (RAG = false: n % 64 == 0, no such step, and none of its code)
+  const int tail = (RAG && ((k_end - k_begin) % KW) != 0) ? nsteps - 1 : -1;
   unsigned long long* tl = nullptr;
   int tli = 0;
   if (ABL == 5) {
@@ -807,8 +816,10 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   }
   dst += (long)blockIdx.y * Bt * n;
   // per-thread source pointers at k_begin; a step advances them by KW elements
-  const T* ap = A + j * n + k_begin + wk * EH + EPL * g;
+  const long ka = k_begin + wk * EH + EPL * g;  // first k of this lane's A fragment in step 0
+  const T* ap = A + j * n + ka;
   const T* pp[NV];
+  long kp[NV];  // first k of the piece in step 0
   int pdst[NV];  // LDS element offset of the piece's first element within a staging buffer
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -819,7 +830,8 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
     const int kq = (vv >> 4) % PPB, bt = (vv >> 4) / PPB;
     long b = bt * 16 + (vv & 15);
     b = b < Bt ? b : Bt - 1;
-    pp[i] = P + b * n + k_begin + 4 * kq;
+    kp[i] = k_begin + 4 * kq;
+    pp[i] = P + b * n + kp[i];
     const int kh = kq / (EH / 4), kk0 = 4 * (kq % (EH / 4));
     const int gg = kk0 / EPL, e0 = kk0 % EPL;
     pdst[i] = (((kh * NBT + bt) * EPL + e0) * 4 + gg) * 16 + (vv & 15);
@@ -835,14 +847,37 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
       for (int e = 0; e < 4; ++e) Pl[buf * STEP + pdst[i] + e * 64] = ps[i][e];
     }
   };
+  // unit u of step `st`: u < NV -> piece u of the P panel, else half (u - NV) of the A fragment
+  auto load_vec = [&](int u, int st, V4 (&av)[2]) {
+    const long o = (long)st * KW;
+    if (u < NV) ps[u < NV ? u : 0] = *reinterpret_cast<const V4*>(pp[u < NV ? u : 0] + o);
+    else av[u - NV] = *reinterpret_cast<const V4*>(ap + o + 4 * (u - NV));
+  };
+  auto load_gen = [&](int u, int st, V4 (&av)[2]) {
+    if (!RAG || st != tail) {
+      load_vec(u, st, av);
+    } else {
+      const long o = (long)st * KW;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (u < NV) {
+          const int i = u < NV ? u : 0;
+          ps[i][e] = kp[i] + o + e < n ? pp[i][o + e] : (T)0;
+        } else {
+          const int q = u - NV;
+          av[q][e] = ka + o + 4 * q + e < n ? ap[o + 4 * q + e] : (T)0;
+        }
+      }
+    }
+  };
   if (nsteps > 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) ps[i] = *reinterpret_cast<const V4*>(pp[i]);
-    a0[0] = *reinterpret_cast<const V4*>(ap);
-    a0[1] = *reinterpret_cast<const V4*>(ap + 4);
-    const long o1 = nsteps > 1 ? KW : 0;
-    a1[0] = *reinterpret_cast<const V4*>(ap + o1);
-    a1[1] = *reinterpret_cast<const V4*>(ap + o1 + 4);
+    for (int u = 0; u < NV; ++u) load_gen(u, 0, a0);
+    load_gen(NV, 0, a0);
+    load_gen(NV + 1, 0, a0);
+    const int s1 = nsteps > 1 ? 1 : 0;
+    load_gen(NV, s1, a1);
+    load_gen(NV + 1, s1, a1);
     stage(0);
   }
   __syncthreads();
@@ -858,16 +893,15 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   // step's 4800 cycles).  The panel of the next step is staged after group 5, by when its loads (requested after
   // groups 0 and 2) have landed.
   T pf[2][NBT];
-  auto do_step = [&](int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+  auto do_step = [&](auto gen_tag, int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+    constexpr bool GEN = decltype(gen_tag)::value;  // this step may request the partial step: checked per unit
     const int buf = s & 1;
-    const long op = (long)(s + 1 < nsteps ? s + 1 : nsteps - 1) * KW;
-    const long oa = (long)(s + 2 < nsteps ? s + 2 : nsteps - 1) * KW;
+    const int sp = s + 1 < nsteps ? s + 1 : nsteps - 1;
+    const int sa = s + 2 < nsteps ? s + 2 : nsteps - 1;
     auto issue = [&](int u) {
-      if (u < NV) {
-        ps[u] = *reinterpret_cast<const V4*>(pp[u] + op);
-      } else if (u < NU) {
-        ain[u - NV] = *reinterpret_cast<const V4*>(ap + oa + 4 * (u - NV));
-      }
+      if (u >= NU) return;
+      if (GEN) load_gen(u, u < NV ? sp : sa, ain);
+      else load_vec(u, u < NV ? sp : sa, ain);
     };
     const T* rd = lds_rd + buf * STEP;
 #pragma unroll
@@ -896,10 +930,16 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   };
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) pf[0][bt] = lds_rd[(bt * EPL) * 64];  // group 0 of step 0 (buffer 0)
+  // steps from gen_from on request the partial step (or, clamped, re-request it)
+  const int gen_from = tail < 0 ? nsteps : (tail - 2 > 0 ? tail - 2 : 0);
+  auto step_any = [&](int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+    if (!RAG || s < gen_from) do_step(std::false_type{}, s, ac, ain);
+    else do_step(std::true_type{}, s, ac, ain);
+  };
   for (int s = 0; s < nsteps; s += 3) {
-    do_step(s, a0, a2);
-    if (s + 1 < nsteps) do_step(s + 1, a1, a0);
-    if (s + 2 < nsteps) do_step(s + 2, a2, a1);
+    step_any(s, a0, a2);
+    if (s + 1 < nsteps) step_any(s + 1, a1, a0);
+    if (s + 2 < nsteps) step_any(s + 2, a2, a1);
   }
   T* red = Pl;
   if (wk == 1) {
@@ -944,7 +984,9 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   // workgroups per CU: two for the narrow panels (Bt <= 32: 28-30 us instead of 33-35 at n = 4096), one for
   // the wide ones, where a second resident workgroup only adds slice partials (measured, MGP_SKINNY_BPC)
   const long bpc = h->skinny_blocks_per_cu > 0 ? h->skinny_blocks_per_cu : (NBT <= 2 ? 2 : 1);
-  long ks = (bpc * h->num_cus + jg - 1) / jg;
+  // wide panels keep ONE resident round: round the slice count down (n = 4032: 63 row blocks x 4 slices = 252
+  // workgroups in one round, not 5 slices = 315 in two: 71.8 -> ~50 us); the narrow ones fill two per CU
+  long ks = bpc == 1 ? (h->num_cus / jg) : (bpc * h->num_cus + jg - 1) / jg;
   if (ks > 16) ks = 16;
   if (ks < 1) ks = 1;
   long kr_len = ((n + ks - 1) / ks + KW - 1) / KW * KW;
@@ -958,14 +1000,21 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   dim3 grid((unsigned)jg, (unsigned)ks);
   bool piped = false;
   if constexpr (NBT == 2 || NBT == 4) {  // Bt <= 16 is bound by the A stream and the round-1 form already runs at it (29.7 vs 34.2 us)
-    if (vec && (n % 64) == 0 && h->skinny_pipe && (h->skinny_stagger <= 100 || h->skinny_stagger == 107)) {
+    if (n >= 256 && h->skinny_pipe && (h->skinny_stagger <= 100 || h->skinny_stagger == 107)) {
       piped = true;
-      if (h->skinny_stagger == 107)
-        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, 5>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst, kr_len,
-                           gate);
+      const bool whole = (n % 64) == 0;
+      if (h->skinny_stagger == 107 && vec && whole)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, true, false, 5>), grid, dim3(512), 0, h->stream, A, n, P, Bt,
+                           dst, kr_len, gate);
+      else if (vec && whole)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, true, false>), grid, dim3(512), 0, h->stream, A, n, P, Bt,
+                           dst, kr_len, gate);
+      else if (vec)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, true, true>), grid, dim3(512), 0, h->stream, A, n, P, Bt,
+                           dst, kr_len, gate);
       else
-        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT>), grid, dim3(512), 0, h->stream, A, n, P, Bt, dst, kr_len,
-                           gate);
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, false, true>), grid, dim3(512), 0, h->stream, A, n, P, Bt,
+                           dst, kr_len, gate);
     }
   }
   if (piped) {
