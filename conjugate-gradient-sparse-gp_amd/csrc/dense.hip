@@ -272,7 +272,9 @@ struct Mfma<float> {
 // (WT = 4: 128x128 tile, the throughput shape; WT = 2: 64x64, used when the 128-tile grid would
 // leave CUs idle).  Operand tiles are register-prefetched one step ahead and staged through LDS
 // with a conflict-free stride.  `upper_only` skips tiles strictly below the diagonal.
-template <typename T, bool VEC, int WT>
+// UA (with VEC = false): any K and leading dimensions -- whole k steps use 16-byte loads that carry element
+// alignment only, the partial last step is loaded element by element with zeros past K.
+template <typename T, bool VEC, int WT, bool UA = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P, long ldp, long m,
                                                       const T* __restrict__ A, long lda, long n, long K,
                                                       T* __restrict__ out, long ldo, int accumulate, int upper_only,
@@ -298,6 +300,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
   P += (long)bz * zstride_k;
   A += (long)bz * zstride_k;
   out += (long)bz * zstride_out;
+  if (UA && zstride_k > 0) {  // UA slices: K is the TOTAL length, a slice is zstride_k long and the last one what is left
+    const long left = K - (long)bz * zstride_k;
+    K = left < zstride_k ? left : zstride_k;
+  }
   constexpr int BM = 32 * WT, BK = 16, LDS_S = BK + 2;  // stride 18: conflict-free b64 reads
   constexpr int EPT = BM * BK / 256;                      // elements per thread and operand per step
   __shared__ __attribute__((aligned(16))) T Ps[BM * LDS_S];
@@ -344,15 +350,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
     }
   };
   load_tiles(0);
-  if constexpr (VEC && WT == 4) {
+  if constexpr ((VEC || UA) && WT == 4) {
     // Throughput shape, whole 16-element k steps: the next step's operand loads carry no predicate (rows beyond
     // m / n are clamped to row 0 and their results never written; the step after the last re-reads the last) and
     // go out in four pairs, one behind each group of 16 MFMAs -- not as a burst of eight in front of them, during
     // which the in-order wave issues no MFMA (the skinny product's timeline).
     constexpr int VW = 16 / sizeof(T);
     constexpr int NL = EPT / VW;  // 16-byte loads per operand, thread and step
-    using V = __attribute__((ext_vector_type(VW))) T;
-    V np[NL], na_[NL];  // staged at the top of the next step straight from these registers: no copy of a load in flight
+    typedef T Vr __attribute__((ext_vector_type(VW)));
+    typedef Vr V __attribute__((aligned(UA ? sizeof(T) : 16)));
+    Vr np[NL], na_[NL];  // staged at the top of the next step straight from these registers: no copy of a load in flight
 #pragma unroll
     for (int u = 0; u < NL; ++u)
 #pragma unroll
@@ -370,7 +377,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
           As[srow * LDS_S + skk + u * VW + x] = na_[u][x];
         }
       __syncthreads();
-      const long kn = (k0 + BK < K ? k0 + BK : k0) + skk;
+      // past the last step the request is a dummy: the current step again, or (UA: it may be the partial one) step 0
+      const long kn = (k0 + BK < K ? k0 + BK : (UA ? 0 : k0)) + skk;
+      const bool part_next = UA && (k0 + BK < K) && (k0 + 2 * BK > K);  // uniform: the step being requested is the partial one
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 4) {
         T af[WT], bf[WT];
@@ -386,8 +395,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
         constexpr int G = (NL + 3) / 4;  // loads per operand behind this group
 #pragma unroll
         for (int u = (ks / 4) * G; u < (ks / 4 + 1) * G && u < NL; ++u) {
-          np[u] = *reinterpret_cast<const V*>(prow + kn + u * VW);
-          na_[u] = *reinterpret_cast<const V*>(arow + kn + u * VW);
+          if (UA && part_next) {
+#pragma unroll
+            for (int x = 0; x < VW; ++x) {
+              const long kk = kn + u * VW + x;
+              np[u][x] = kk < K ? prow[kk] : (T)0;
+              na_[u][x] = kk < K ? arow[kk] : (T)0;
+            }
+          } else {
+            np[u] = *reinterpret_cast<const V*>(prow + kn + u * VW);
+            na_[u] = *reinterpret_cast<const V*>(arow + kn + u * VW);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -463,8 +481,15 @@ int gemm_nt_launch(mgp_handle* h, const T* P, long ldp, long m, const T* A, long
                        ldo, accumulate, 0, gate, 0L, 0L, (const int*)nullptr, 0);                                \
   } while (0)
   if (big >= 2L * h->num_cus) {
-    if (vec) MGP_GEMM(true, 4);
-    else MGP_GEMM(false, 4);
+    if (vec) {
+      MGP_GEMM(true, 4);
+    } else if (K >= 32) {  // ragged K / unaligned rows: element-aligned vector loads, element-wise partial step
+      dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128));
+      hipLaunchKernelGGL((gemm_nt_kernel<T, false, 4, true>), grid, dim3(256), 0, h->stream, P, ldp, m, A, lda, n, K,
+                         out, ldo, accumulate, 0, gate, 0L, 0L, (const int*)nullptr, 0);
+    } else {
+      MGP_GEMM(false, 4);
+    }
   } else {
     long nz = (2L * h->num_cus + big - 1) / big;
     if (nz > 8) nz = 8;
@@ -479,6 +504,27 @@ int gemm_nt_launch(mgp_handle* h, const T* P, long ldp, long m, const T* A, long
       MGP_LAUNCH_CHECK(h);
       hipLaunchKernelGGL((gemm_slices_sum_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
                          (const T*)part, tot, (int)nz, out, gate);
+    } else if (h->gemm_ksplit && !vec && !accumulate && ldo == n && K >= 512) {
+      // ragged K / unaligned rows, mid-size shape: the same 128x128 tile over slices, through the UA loads
+      long nzu = (2L * h->num_cus + big - 1) / big;
+      if (nzu > 8) nzu = 8;
+      while (nzu > 1 && K / nzu < 256) --nzu;
+      const long ksl = ((K + nzu - 1) / nzu + 15) / 16 * 16;
+      nzu = (K + ksl - 1) / ksl;
+      const long tot = m * n;
+      T* part = out;
+      if (nzu > 1) {
+        MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nzu * tot * sizeof(T)));
+        part = (T*)h->ws;
+      }
+      dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), (unsigned)nzu);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, false, 4, true>), grid, dim3(256), 0, h->stream, P, ldp, m, A, lda, n, K,
+                         part, n, 0, 0, gate, nzu > 1 ? ksl : 0L, nzu > 1 ? tot : 0L, (const int*)nullptr, 0);
+      if (nzu > 1) {
+        MGP_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL((gemm_slices_sum_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                           (const T*)part, tot, (int)nzu, out, gate);
+      }
     } else {
       if (vec) MGP_GEMM(true, 2);
       else MGP_GEMM(false, 2);

@@ -345,6 +345,21 @@ def test_symm_matmul_pipelined_form(n, Bt, monkeypatch):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("n,Bt", [(4001, 2100), (1001, 700), (4001, 300), (530, 129), (999, 1000)])
+def test_symm_matmul_ragged_gemm_regime(n, Bt):
+    """Bt > 128 with n not a multiple of 16 (or of 2): the GEMM's element-aligned vector loads and its element-wise
+    partial last step -- full-grid form (4001 x 2100), sliced forms, and a last slice shorter than the others."""
+    from cggp import ops
+    rng = np.random.default_rng(n * 7 + Bt)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    P = rng.standard_normal((Bt, n))
+    out = ops.symm_matmul(T(A), T(P))
+    assert relerr(out, P @ A) < 1e-12
+    out32 = ops.symm_matmul(T(A, torch.float32), T(P, torch.float32))
+    assert relerr(out32, P @ A) < 2e-4
+
+
 @pytest.mark.parametrize("Bt", [1, 8, 33, 200])
 def test_symm_matmul_fp32(Bt):
     from cggp import ops
