@@ -657,6 +657,8 @@ __global__ __launch_bounds__(512) void symm_skinny_kernel(const T* __restrict__ 
 // original [Bt,n] layout (no transpose pass).
 constexpr int TLW = 128;  // timeline words per workgroup (ABL 5/6)
 
+// VEC: n % 4 == 0 and 32-byte aligned bases (naturally aligned 32-byte loads); otherwise the same loads carry
+// element alignment only and a group of four that straddles n is read element by element.
 template <typename T, int NBT, int KW, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restrict__ A, long n,
                                                               const T* __restrict__ P, long Bt,
@@ -692,17 +694,16 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
 
   T a[EPL], an[EPL], ps[NV][4];
   auto load4 = [&](const T* base, long k, bool ok, T* v) {
-    if (VEC) {
-      if (ok && k + 3 < n) {
-        using V4 = __attribute__((ext_vector_type(4))) T;
-        const V4 x = *reinterpret_cast<const V4*>(base + k);
-        v[0] = x[0];
-        v[1] = x[1];
-        v[2] = x[2];
-        v[3] = x[3];
-      } else {
-        v[0] = v[1] = v[2] = v[3] = (T)0;
-      }
+    typedef T V4r __attribute__((ext_vector_type(4)));
+    typedef V4r V4 __attribute__((aligned(VEC ? 4 * sizeof(T) : sizeof(T))));
+    if (ok && k + 3 < n) {
+      const V4r x = *reinterpret_cast<const V4*>(base + k);
+      v[0] = x[0];
+      v[1] = x[1];
+      v[2] = x[2];
+      v[3] = x[3];
+    } else if (VEC) {
+      v[0] = v[1] = v[2] = v[3] = (T)0;  // n % 4 == 0: a group is whole or beyond n
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (ok && k + e < n) ? base[k + e] : (T)0;
@@ -1030,9 +1031,9 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   // workgroups per CU: two for the narrow panels (Bt <= 32: 28-30 us instead of 33-35 at n = 4096), one for
   // the wide ones, where a second resident workgroup only adds slice partials (measured, MGP_SKINNY_BPC)
   const long bpc = h->skinny_blocks_per_cu > 0 ? h->skinny_blocks_per_cu : (NBT <= 2 ? 2 : 1);
-  // wide panels keep ONE resident round: round the slice count down (n = 4032: 63 row blocks x 4 slices = 252
-  // workgroups in one round, not 5 slices = 315 in two: 71.8 -> ~50 us); the narrow ones fill two per CU
-  long ks = bpc == 1 ? (h->num_cus / jg) : (bpc * h->num_cus + jg - 1) / jg;
+  // ONE resident round: the slice count is rounded down (n = 4032, Bt = 64: 63 row blocks x 4 slices = 252
+  // workgroups, not 5 slices = 315 in two rounds: 71.8 -> 50.6 us; n = 4001, Bt = 8: 9 -> 8 slices)
+  long ks = bpc * h->num_cus / jg;
   if (ks > 16) ks = 16;
   if (ks < 1) ks = 1;
   long kr_len = ((n + ks - 1) / ks + KW - 1) / KW * KW;
