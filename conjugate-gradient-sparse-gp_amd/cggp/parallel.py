@@ -114,7 +114,7 @@ class AllReduce:
     def __call__(self, t):
         if self.comm is not None:
             self.comm.allreduce(t)
-        elif t.is_cuda:  # gloo: stage through the host
+        elif t.is_cuda and self.host_staged:  # gloo: stage through the host
             c = t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(c)

@@ -117,6 +117,52 @@ def test_native_rccl_path_is_bit_identical_on_one_rank():
     assert out.returncode == 0 and "NATIVE_OK" in out.stdout, out.stderr[-3000:]
 
 
+_FALLBACK_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path[:0] = [{root!r}, {pkg!r}]
+    from cggp import kernels, parallel
+    from cggp.conjugate_gradient import ConjugateGradient, SgprNormalOperator
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+
+    class Broken:
+        def __init__(self, group=None, device=None):
+            raise RuntimeError("communicator bootstrap failed (scripted)")
+    parallel.Communicator = Broken
+    ar = parallel.make_allreduce(force=True)
+    assert ar is not None and ar.comm is None and "scripted" in ar.native_error
+    rng = np.random.default_rng(0)
+    N, D, M = 6000, 3, 64
+    X = rng.standard_normal((N, D)); Z = X[rng.choice(N, M, replace=False)]; rhs = rng.standard_normal((M, 2))
+    Xt, Zt, bt = (torch.from_numpy(a).to(dev) for a in (X, Z, rhs))
+    kern = kernels.SquaredExponential(1.2, [0.8, 1.0, 1.3])
+    op_c = SgprNormalOperator(kern, Xt, Zt, 0.1, jitter=1e-6, allreduce=ar, kmm_rows=parallel.kmm_slab(M))
+    st, keep = op_c._struct()
+    assert not st.comm and st.allreduce  # the callback hook, reaching torch.distributed's RCCL on device tensors
+    op_0 = SgprNormalOperator(kern, Xt, Zt, 0.1, jitter=1e-6)
+    cg = ConjugateGradient(1e-12, max_iterations=500, check_every=7)
+    sc, (kc, ec) = cg.solve_with_stats(op_c, bt)
+    s0, (k0, e0) = cg.solve_with_stats(op_0, bt)
+    assert int(kc) == int(k0) and torch.equal(sc, s0) and torch.equal(ec, e0)
+    t = torch.arange(10, dtype=torch.float64, device=dev); ar(t)
+    assert torch.equal(t, torch.arange(10, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("FALLBACK_OK")
+""")
+
+
+def test_nccl_group_falls_back_to_torch_all_reduce_when_the_native_communicator_fails():
+    """parallel.AllReduce on backend "nccl": when libmgp's communicator cannot be created on some rank every rank
+    agrees (one all-reduce) to use torch.distributed's all_reduce on the device tensor through the callback hook."""
+    code = _FALLBACK_WORKER.format(root=ROOT, pkg=PKG, port=_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "FALLBACK_OK" in out.stdout, out.stderr[-3000:]
+
+
 class _ScriptedSecondRank:
     """Stands in for rank 1 of a 2-rank job through the callback hook: it holds no rows (zero partial)
     and reports `active` for the first `agree` operator applications only."""
