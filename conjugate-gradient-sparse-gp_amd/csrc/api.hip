@@ -46,6 +46,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (sst && atoi(sst) >= 0 && atoi(sst) <= 200) h->skinny_stagger = atoi(sst);
   const char* sk = getenv("MGP_SKINNY");
   if (sk && strcmp(sk, "reg") == 0) h->skinny_mode = 0;
+  const char* skd = getenv("MGP_SKINNY_DEFER");
+  if (skd && strcmp(skd, "0") == 0) h->skinny_defer = 0;
   const char* skp = getenv("MGP_SKINNY_PIPE");
   if (skp && strcmp(skp, "0") == 0) h->skinny_pipe = 0;
   const char* tm = getenv("MGP_TRI_MIN_N");

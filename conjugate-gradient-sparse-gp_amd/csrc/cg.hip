@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
                                                              const T* __restrict__ ap, T* __restrict__ rz,
                                                              int* __restrict__ over, T* __restrict__ err, long n,
                                                              T thr, T min_float, const T* __restrict__ dinv,
-                                                             int max_it) {
+                                                             int max_it, int ap_slices, long ap_stride) {
   if (ctrl->active == 0) return;
   __shared__ T red[2][NT / 64];
   __shared__ int last_flag;
@@ -189,8 +189,28 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
     pv[e] = ok ? p[off + j] : (T)0;
     av[e] = ok ? ap[off + j] : (T)0;
     rv[e] = ok ? r[off + j] : (T)0;
-    d = mgp_fma(pv[e], av[e], d);
   }
+  if (ap_slices > 1) {
+    // A.p left as contraction slices by the skinny product (at most 8): every slice of every element is requested
+    // before the first is used -- one workgroup per right-hand side is latency-bound, a load-add chain per element
+    // cost what the separate reduce launch had -- then added in slice order, as skinny_reduce_kernel does
+    T sl[7][EPT];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const long j = (long)e * NT + t;
+        sl[z - 1][e] = (z < ap_slices && j < n) ? ap[(long)z * ap_stride + off + j] : (T)0;
+      }
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+      if (z < ap_slices) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) av[e] += sl[z - 1][e];
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) d = mgp_fma(pv[e], av[e], d);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
   if (lane == 0) red[0][wave] = d;
@@ -549,12 +569,26 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     if (enq + batch > max_it) batch = max_it - enq;
     for (long q = 0; q < batch; ++q, ++enq) {
       const bool reset = (enq % cycle) == (cycle - 1);  // :71 (enq == state.i while active)
-      MGP_TRY(apply_operator<T>(h, op, p, Bt, ap, &ctrl->active));
+      // dense operator + fused update: the skinny product may leave its slices for the update to add
+      const bool defer = !reset && fused_ept > 0 && op->kind == MGP_OP_DENSE && h->skinny_defer;
+      h->defer_slices = defer;
+      h->deferred_ks = 1;
+      const int rc_apply = apply_operator<T>(h, op, p, Bt, ap, &ctrl->active);
+      h->defer_slices = false;
+      MGP_TRY(rc_apply);
       if (!reset && fused_ept > 0) {
         const T* dinv = pc.kind == MGP_PRE_JACOBI ? (const T*)pc.diag_inv : nullptr;
+        const T* ap_src = ap;
+        int ap_slices = 1;
+        long ap_stride = 0;
+        if (defer && h->deferred_ks > 1) {
+          ap_src = (const T*)h->deferred_part;
+          ap_slices = h->deferred_ks;
+          ap_stride = h->deferred_stride;
+        }
 #define MGP_FUSED(EPTV, NTV)                                                                                   \
-  hipLaunchKernelGGL((cg_update_fused_kernel<T, EPTV, NTV>), dim3((unsigned)Bt), dim3(NTV), 0, s, ctrl, V, r, p, ap, \
-                     rz, over, err_out, n, (T)thr, (T)min_float, dinv, (int)max_it)
+  hipLaunchKernelGGL((cg_update_fused_kernel<T, EPTV, NTV>), dim3((unsigned)Bt), dim3(NTV), 0, s, ctrl, V, r, p,    \
+                     ap_src, rz, over, err_out, n, (T)thr, (T)min_float, dinv, (int)max_it, ap_slices, ap_stride)
         switch (fused_ept) {
           case 1: MGP_FUSED(1, 256); break;
           case 2: MGP_FUSED(2, 256); break;

@@ -1121,6 +1121,12 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
       }
     }
   }
+  if (ks > 1 && ks <= 8 && h->defer_slices) {  // the caller (the fused CG update) sums the slices as it reads them
+    h->deferred_part = dst;
+    h->deferred_ks = (int)ks;
+    h->deferred_stride = Bt * n;
+    return MGP_OK;
+  }
   if (ks > 1) {
     const long tot = Bt * n;
     hipLaunchKernelGGL((skinny_reduce_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,

@@ -72,6 +72,14 @@ struct mgp_handle {
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
   int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
   int skinny_stagger = 0;  // experiment (MGP_SKINNY_STAGGER): start-up delay units between workgroup phases
+  // Deferred slice sum of the skinny product (dense.hip -> cg.hip): while `defer_slices` is set the product leaves its
+  // contraction slices in `ws` instead of launching skinny_reduce_kernel and reports them here; the fused CG update
+  // adds them in slice order as it reads A.p (the same sums in the same order, one launch fewer per iteration).
+  bool defer_slices = false;
+  const void* deferred_part = nullptr;
+  int deferred_ks = 1;
+  long deferred_stride = 0;
+  int skinny_defer = 1;  // MGP_SKINNY_DEFER=0 keeps the separate reduce launch inside the CG loop
   int skinny_pipe = 1;  // software-pipelined form of the LDS-staged product when n % 64 == 0 and Bt <= 64 (MGP_SKINNY_PIPE=0: the round-1 form)
   int skinny_mode = 1;  // 2 <= Bt <= 128 product: 1 = P staged through LDS, 0 = register operands (MGP_SKINNY=reg)
   int nosplit_per_cu = 4;  // owned-side workgroups per CU above which the streamed set is not split (MGP_NOSPLIT_PER_CU)
