@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long off = (long)blockIdx.x * n;
   const T rz_old = rz[blockIdx.x];
-  T pv[EPT], av[EPT], rv[EPT];
+  T pv[EPT], av[EPT], rv[EPT], vv[EPT], dv[EPT];
   T d = 0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
@@ -189,6 +189,10 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
     pv[e] = ok ? p[off + j] : (T)0;
     av[e] = ok ? ap[off + j] : (T)0;
     rv[e] = ok ? r[off + j] : (T)0;
+    // the solution and the Jacobi diagonal are not needed before gamma is known, but requested now: behind the
+    // block reduction they were a third dependent round trip to memory in a kernel that is nothing but latency
+    vv[e] = ok ? v[off + j] : (T)0;
+    dv[e] = (dinv != nullptr && ok) ? dinv[j] : (T)0;
   }
   if (ap_slices > 1) {
     // A.p left as contraction slices by the skinny product (at most 8): every slice of every element is requested
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const long j = (long)e * NT + t;
-    if (j < n) v[off + j] = mgp_fma(gamma, pv[e], v[off + j]);
+    if (j < n) v[off + j] = mgp_fma(gamma, pv[e], vv[e]);
     rv[e] = mgp_fma(-gamma, av[e], rv[e]);
-    zv[e] = dinv != nullptr ? (j < n ? rv[e] * dinv[j] : (T)0) : rv[e];
+    zv[e] = dinv != nullptr ? rv[e] * dv[e] : rv[e];
     s_rz = mgp_fma(zv[e], rv[e], s_rz);
     s_rr = mgp_fma(rv[e], rv[e], s_rr);
   }
