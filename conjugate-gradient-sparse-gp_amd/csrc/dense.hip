@@ -1030,7 +1030,8 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   const long jg = (n + 63) / 64;
   // workgroups per CU: two for the narrow panels (Bt <= 32: 28-30 us instead of 33-35 at n = 4096), one for
   // the wide ones, where a second resident workgroup only adds slice partials (measured, MGP_SKINNY_BPC)
-  const long bpc = h->skinny_blocks_per_cu > 0 ? h->skinny_blocks_per_cu : (NBT <= 2 ? 2 : 1);
+  // (the pipelined kernel, 16 < Bt <= 64, prefers one as well since round 2: Bt = 32, n = 4096: 33.6 vs 36.9 us)
+  const long bpc = h->skinny_blocks_per_cu > 0 ? h->skinny_blocks_per_cu : (NBT <= 1 ? 2 : 1);
   // ONE resident round: the slice count is rounded down (n = 4032, Bt = 64: 63 row blocks x 4 slices = 252
   // workgroups, not 5 slices = 315 in two rounds: 71.8 -> 50.6 us; n = 4001, Bt = 8: 9 -> 8 slices)
   long ks = bpc * h->num_cus / jg;
