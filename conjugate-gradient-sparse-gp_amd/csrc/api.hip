@@ -73,6 +73,13 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
     delete h;
     return MGP_E_NOMEM;
   }
+  if (mgp_build_e2tabs(h) != MGP_OK) {
+    (void)hipFree(h->dparams);
+    (void)hipFree(h->ones);
+    (void)hipHostFree(h->host_flag);
+    delete h;
+    return MGP_E_NOMEM;
+  }
   *out = h;
   return MGP_OK;
 }
@@ -113,6 +120,7 @@ extern "C" int mgp_destroy(mgp_handle* h) {
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);
+  if (h->e2tabs) (void)hipFree(h->e2tabs);
   for (auto& pr : h->prof_ev) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);

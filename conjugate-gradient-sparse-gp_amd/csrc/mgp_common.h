@@ -48,6 +48,7 @@ struct mgp_handle {
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
+  void* e2tabs = nullptr;  // exp2 tables of the fast fp64 sweep (8192 + 2048 entries, sweep.hip: mgp_build_e2tabs)
   double* dparams = nullptr;  // device copy of c/lengthscale_d for the generic-D kernels [MGP_MAX_D]
   int num_cus = 256;
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
@@ -173,6 +174,8 @@ inline int mgp_reserve(mgp_handle* h, void** p, size_t* have, size_t need) {
   *have = want;
   return MGP_OK;
 }
+
+int mgp_build_e2tabs(mgp_handle* h);  // sweep.hip
 
 inline size_t mgp_elem(int dtype) { return dtype == MGP_F64 ? 8 : 4; }
 

@@ -388,6 +388,16 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const double* __
   for (int e = t; e < cnt; e += 256) dst[e] = rows[(e / RC) * (RC + 1) + (e % RC)];  // RC is a power of two
 }
 
+// T'[e] = 2^(e / 2^TBITS) with e << (20 - TBITS) subtracted from its high word (see below); one copy per handle
+template <int TBITS>
+__global__ __launch_bounds__(256) void build_e2tab_kernel(double* __restrict__ tab) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= (1 << TBITS)) return;
+  unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2((double)e * (1.0 / (1 << TBITS))));
+  bits -= (unsigned long long)e << (20 - TBITS + 32);  // high word -= e << (20 - TBITS)
+  tab[e] = __builtin_bit_cast(double, bits);
+}
+
 // NT threads per workgroup share one table of 2^TBITS entries (t = m / 2^TBITS + g, |g| <= 2^-(TBITS+1)):
 //   TBITS 11, NT 256: 16 KB, several workgroups per CU; byte offset of the entry by shift + and;
 //   TBITS 13, NT 512: 64 KB, two workgroups per CU; the offset is ONE instruction -- an SDWA shift that
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT 
     const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_sr, long o_chunk, int D,
     SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, long ad_sr,
     const int* __restrict__ gate, int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits,
-    int pf_mask, int pf_ahead) {
+    int pf_mask, int pf_ahead, const double* __restrict__ gtab) {
   if (gate != nullptr && *gate == 0) return;
   const int lin = blockIdx.x;
   int bx, by;
@@ -434,11 +444,11 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT 
   __shared__ double e2tab[TSIZE];
   __shared__ unsigned long long amax_w[NT / 64];
   const int t = threadIdx.x;
-  for (int e = t; e < TSIZE; e += NT) {
-    unsigned long long bits = __builtin_bit_cast(unsigned long long, mgp_exp2((double)e * (1.0 / TSIZE)));
-    bits -= (unsigned long long)e << (20 - TBITS + 32);  // high word -= e << (20 - TBITS)
-    e2tab[e] = __builtin_bit_cast(double, bits);
-  }
+  // the table is copied from the handle's device copy (build_e2tab_kernel, once per handle): computing its 16
+  // entries per thread was 700 instructions in front of every workgroup -- 5-8 % of a workgroup that streams
+  // 256 points (a rank's share of C3), <1 % of one that streams 2048
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  for (int e = 2 * t; e < TSIZE; e += 2 * NT) *reinterpret_cast<d2*>(&e2tab[e]) = *reinterpret_cast<const d2*>(gtab + e);
   const long base = (long)bx * (NT * RPT);
   double a[RPT][DP], cq[RPT], acc[RPT][RC];  // cq: SE -> MAGIC - |a|^2 ; Matern -> |a|^2
   unsigned long long amax = 0;            // bit pattern of max |a|^2: orders like the value, NaN above everything
@@ -906,7 +916,8 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
 #define MGP_FAST_LAUNCH(RPTV, NTV, TB, DB)                                                                       \
   hipLaunchKernelGGL((sweep_fast_kernel<DP, KIND, RC, RPTV, NTV, TB, DB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, \
                      nb, b_chunk, W, w_sj, dst, d_si, d_sr, d_chunk, D, prm, a_alpha, a_add, a_si, a_sr, gate,        \
-                     (int)nblk, (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead)
+                     (int)nblk, (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead,                                    \
+                     (const double*)h->e2tabs + (TB == 13 ? 0 : 8192))
       if constexpr (RC > 1) {
         // two SGPR copies of (row, weights) while they fit: (DP + 1 + RC) doubles each
         if constexpr (DP > 16) {
@@ -1116,4 +1127,14 @@ extern "C" int mgp_kmn_matvec(mgp_handle* h, const mgp_kernel* k, const void* X,
   if (!h) return MGP_E_BADARG;
   return mgp_sweep(h, k, Z, M, X, N, mgp_view(W, N, R, w_layout), R, mgp_view_mut(out, M, R, out_layout), 0.0,
                    VecView{nullptr, 0, 0}, nullptr);
+}
+
+// Device copies of the fast sweep's two exp2 tables (8192 + 2048 entries), built once per handle (mgp_create*).
+int mgp_build_e2tabs(mgp_handle* h) {
+  MGP_HIP(h, hipMalloc(&h->e2tabs, (8192 + 2048) * sizeof(double)));
+  hipLaunchKernelGGL((build_e2tab_kernel<13>), dim3(32), dim3(256), 0, nullptr, (double*)h->e2tabs);
+  hipLaunchKernelGGL((build_e2tab_kernel<11>), dim3(8), dim3(256), 0, nullptr, (double*)h->e2tabs + 8192);
+  MGP_LAUNCH_CHECK(h);
+  MGP_HIP(h, hipDeviceSynchronize());
+  return MGP_OK;
 }
