@@ -820,19 +820,24 @@ __global__ __launch_bounds__(512) void symm_skinny_lds_kernel(const T* __restric
 //   * operand fragments of MFMA group e+1 are read from LDS before group e is issued (explicitly: the
 //     scheduling barriers that fix the load positions also stop the compiler from doing it).
 // Same lane/element mapping and the same order of accumulation as the kernel above: bit-identical results.
-template <typename T, int NBT, bool AL, bool RAG, int ABL = 0>
+// KW: k per step -- 64 (two staging buffers of NBT <= 4 panels fit 64 KB) or 32 (NBT = 8: Bt up to 128)
+template <typename T, int NBT, bool AL, bool RAG, int ABL = 0, int KW = 64>
 __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restrict__ A, long n,
                                                                const T* __restrict__ P, long Bt,
                                                                T* __restrict__ dst, long kr_len,
                                                                const int* __restrict__ gate) {
   if (gate != nullptr && *gate == 0) return;
-  constexpr int KW = 64, EH = 32, EPL = 8, PPB = 16;
+  constexpr int EH = KW / 2, EPL = EH / 4, PPB = KW / 4, NA = EPL / 4;  // NA: 32-byte units of the A fragment
+  static_assert(KW == 64 || KW == 32, "k per step");
   constexpr int STEP = NBT * 16 * KW;
   constexpr int NPIECE = NBT * 16 * PPB;
   constexpr int NV = (NPIECE + 511) / 512;
   constexpr int REDN = NBT * 1024;
   constexpr int LDSN = 2 * STEP > REDN ? 2 * STEP : REDN;
-  constexpr int NU = 2 + NV;  // 32-byte load units per thread and step: 2 of A, NV of P
+  constexpr int NU = NA + NV;  // 32-byte load units per thread and step: NA of A, NV of P
+  constexpr int ISTEP = EPL == 8 ? 2 : 1;     // a request behind every ISTEP-th MFMA group
+  constexpr int STAGE_AT = EPL == 8 ? 5 : 2;  // the group behind which the next panel is staged
+  static_assert(NU * ISTEP <= EPL - 1 + ISTEP && NU <= 4, "requests fit the groups in front of the barrier");
   using Acc = typename Mfma<T>::Acc;
   typedef T V4r __attribute__((ext_vector_type(4)));
   // AL: n % 4 == 0 and 32-byte aligned bases -> naturally aligned 32-byte loads; otherwise rows start at arbitrary
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   Acc acc[NBT];
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) acc[bt] = Acc{0, 0, 0, 0};
-  V4 a0[2], a1[2], a2[2], ps[NV];
+  V4 a0[NA], a1[NA], a2[NA], ps[NV];
   auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -895,12 +900,12 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
     }
   };
   // unit u of step `st`: u < NV -> piece u of the P panel, else half (u - NV) of the A fragment
-  auto load_vec = [&](int u, int st, V4 (&av)[2]) {
+  auto load_vec = [&](int u, int st, V4 (&av)[NA]) {
     const long o = (long)st * KW;
     if (u < NV) ps[u < NV ? u : 0] = *reinterpret_cast<const V4*>(pp[u < NV ? u : 0] + o);
     else av[u - NV] = *reinterpret_cast<const V4*>(ap + o + 4 * (u - NV));
   };
-  auto load_gen = [&](int u, int st, V4 (&av)[2]) {
+  auto load_gen = [&](int u, int st, V4 (&av)[NA]) {
     if (!RAG || st != tail) {
       load_vec(u, st, av);
     } else {
@@ -920,11 +925,11 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   if (nsteps > 0) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) load_gen(u, 0, a0);
-    load_gen(NV, 0, a0);
-    load_gen(NV + 1, 0, a0);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) load_gen(NV + q, 0, a0);
     const int s1 = nsteps > 1 ? 1 : 0;
-    load_gen(NV, s1, a1);
-    load_gen(NV + 1, s1, a1);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) load_gen(NV + q, s1, a1);
     stage(0);
   }
   __syncthreads();
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   // step's 4800 cycles).  The panel of the next step is staged after group 5, by when its loads (requested after
   // groups 0 and 2) have landed.
   T pf[2][NBT];
-  auto do_step = [&](auto gen_tag, int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+  auto do_step = [&](auto gen_tag, int s, const V4 (&ac)[NA], V4 (&ain)[NA]) {
     constexpr bool GEN = decltype(gen_tag)::value;  // this step may request the partial step: checked per unit
     const int buf = s & 1;
     const int sp = s + 1 < nsteps ? s + 1 : nsteps - 1;
@@ -958,9 +963,9 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
       const T av = ac[e >> 2][e & 3];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[e & 1][bt], av, acc[bt]);
-      // NU <= 4 units over 8 groups: one after every second group (the last groups stay free of requests)
-      if ((e & 1) == 0) issue(e >> 1);
-      if (e == 5) stage(buf ^ 1);  // unconditional (see above); after the last step that buffer is not read again
+      // NU <= 4 units over the groups in front of the barrier, the last groups free of requests
+      if (e % ISTEP == 0) issue(e / ISTEP);
+      if (e == STAGE_AT) stage(buf ^ 1);  // unconditional (see above); after the last step that buffer is not read again
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) pf[0][bt] = rn[(bt * EPL) * 64];
     {
-      const T av = ac[1][3];
+      const T av = ac[(EPL - 1) >> 2][(EPL - 1) & 3];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) acc[bt] = Mfma<T>::run(pf[1][bt], av, acc[bt]);
     }
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(512) void symm_skinny_pipe_kernel(const T* __restri
   for (int bt = 0; bt < NBT; ++bt) pf[0][bt] = lds_rd[(bt * EPL) * 64];  // group 0 of step 0 (buffer 0)
   // steps from gen_from on request the partial step (or, clamped, re-request it)
   const int gen_from = tail < 0 ? nsteps : (tail - 2 > 0 ? tail - 2 : 0);
-  auto step_any = [&](int s, const V4 (&ac)[2], V4 (&ain)[2]) {
+  auto step_any = [&](int s, const V4 (&ac)[NA], V4 (&ain)[NA]) {
     if (!RAG || s < gen_from) do_step(std::false_type{}, s, ac, ain);
     else do_step(std::true_type{}, s, ac, ain);
   };
@@ -1047,6 +1052,21 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   const bool vec = (n % 4) == 0 && (((uintptr_t)A) % 32) == 0 && (((uintptr_t)P) % 32) == 0;
   dim3 grid((unsigned)jg, (unsigned)ks);
   bool piped = false;
+  if constexpr (NBT == 8) {  // 64 < Bt <= 128: the same pipeline over 32-wide k steps (two panels of 8 tiles in 64 KB)
+    if (n >= 256 && h->skinny_pipe && h->skinny_stagger <= 100) {
+      piped = true;
+      const bool whole = (n % 32) == 0;
+      if (vec && whole)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, true, false, 0, 32>), grid, dim3(512), 0, h->stream, A, n, P,
+                           Bt, dst, kr_len, gate);
+      else if (vec)
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, true, true, 0, 32>), grid, dim3(512), 0, h->stream, A, n, P,
+                           Bt, dst, kr_len, gate);
+      else
+        hipLaunchKernelGGL((symm_skinny_pipe_kernel<T, NBT, false, true, 0, 32>), grid, dim3(512), 0, h->stream, A, n, P,
+                           Bt, dst, kr_len, gate);
+    }
+  }
   if constexpr (NBT == 2 || NBT == 4) {  // Bt <= 16 is bound by the A stream and the round-1 form already runs at it (29.7 vs 34.2 us)
     if (n >= 256 && h->skinny_pipe && (h->skinny_stagger <= 100 || h->skinny_stagger == 107)) {
       piped = true;

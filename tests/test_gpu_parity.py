@@ -321,9 +321,10 @@ def test_symm_matmul_fp64(n, Bt):
 
 
 @pytest.mark.parametrize("n", [64, 128, 256, 257, 300, 1000, 1280, 2047, 2048, 3072, 4001, 4608])
-@pytest.mark.parametrize("Bt", [17, 32, 33, 48, 64])
+@pytest.mark.parametrize("Bt", [17, 32, 33, 48, 64, 65, 100, 128])
 def test_symm_matmul_pipelined_form(n, Bt, monkeypatch):
-    """n >= 256 and 16 < Bt <= 64 take the software-pipelined kernel (step counts per slice covering every
+    """n >= 256 and 16 < Bt <= 128 take the software-pipelined kernel (64-wide k steps up to Bt = 64, 32-wide
+    beyond; step counts per slice covering every
     remainder of its loop unrolled by three; Bt not a multiple of 16 exercises the clamped panel rows; n not a
     multiple of 64 / of 4 the element-wise partial step and the element-aligned vector loads).
     Checked against numpy and, bit for bit, against the round-1 form run on a second handle."""
