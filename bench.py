@@ -321,7 +321,9 @@ def main():
                               "matrix and vector peaks are the same 78.6 TFLOP/s on the same ALUs, measured and "
                               "rejected) and is not HBM-bound (SURVEY 8d) -- the hbm figures BASELINE.json asks for "
                               "are in the nested object",
-                "kernel": (f"sweep_se_fast_kernel<{D},4,512,13>" if esize == 8 and kname == "se" and D <= 8 else
+                "kernel": (f"sweep_fast_kernel<{D},{kname},RC=1,RPT=4,512 threads,2^13-entry table>"
+                           if esize == 8 and D <= 8 else
+                           f"sweep_fast_kernel<{D},{kname},RC=1>" if esize == 8 else
                            f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1>") +
                           " (K_nm.p and K_mn.u are the same symbol)",
                 "achieved": ach_tflops, "peak": vector_peak, "unit": "TFLOP/s",

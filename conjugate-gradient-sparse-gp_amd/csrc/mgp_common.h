@@ -54,9 +54,9 @@ struct mgp_handle {
   // 0 = fused sweeps on the VALU (sweep.hip, default: measured faster), 1 = fp64 distance
   // cross-term on the matrix cores (sweep_mfma.hip); MGP_SWEEP=mfma selects 1 for A/B runs
   int sweep_mode = 0;
-  // fp64 SE, D <= 8, one right-hand side: sweep_se_fast_kernel (scalar-loaded packed points, integer exponent
-  // scaling) with 1 = 256 threads / 2048-entry table, 2 = 512 threads / 8192-entry table and a one-instruction
-  // table offset; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
+  // fp64 sweeps: sweep_fast_kernel (scalar-loaded packed points, integer exponent scaling) with 1 = 256 threads /
+  // 2048-entry table (one right-hand side only), 2 = 512 threads / 8192-entry table and a one-instruction table
+  // offset at D <= 16; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
   int sweep_fast = 2;
   int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
   int sweep_target_per_cu = 8;  // chunking of the streamed set aims at this many 256-thread workgroups per CU (MGP_SWEEP_TARGET)

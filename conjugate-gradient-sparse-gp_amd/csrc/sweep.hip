@@ -294,7 +294,8 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
 }
 
 
-// ---- fp64 squared-exponential fast path (D <= 8, one right-hand side: the CG case) -------------
+// ---- fp64 fast path (every profile, D <= 32, 1 / 2 / 4 / 8 right-hand sides per launch) ---------------
+// (written first for SE, D <= 8, one right-hand side -- the CG case -- and described for it:)
 // Same arithmetic as the FAST branch of sweep_kernel, re-laid-out for the issue ports of a CDNA4
 // CU (profiles/r02_valu_issue_probe.txt: a VALU-bound loop pays ~0.7-0.8 of an fp64 slot for every
 // 32-bit integer op and for every per-lane LDS gather, and nothing for scalar loads):
