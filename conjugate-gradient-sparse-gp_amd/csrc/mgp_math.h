@@ -105,9 +105,12 @@ MGP_HD float mgp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c)
 MGP_HD double mgp_sqrt(double x) { return __builtin_sqrt(x); }
 
 // sqrt for x known to be a positive normal number well inside the exponent range (the Matern
-// profiles clamp their argument to >= c^2 * 1e-36): v_rsq_f64 seed + Goldschmidt step + two
-// residual corrections, without the range scaling and special-case selects of the generic
-// lowering (10 instructions instead of ~17 in an fp64-VALU-bound loop).
+// profiles clamp their argument to >= c^2 * 1e-36): v_rsq_f64 seed + Goldschmidt step + ONE
+// residual correction, without the range scaling and special-case selects of the generic
+// lowering (8 instructions instead of ~17 in an fp64-VALU-bound loop).  The generic lowering's second
+// correction only buys correct rounding: after the Goldschmidt step the error is the square of the seed's
+// (2^-46 from a 2^-23 seed), after one correction its square again -- the result is within an ulp, and a
+// Matern kernel value moves by q * 2^-53 of itself (round 2: 57.3 -> 55.3 instructions per pair at C5).
 MGP_HD double mgp_sqrt_pos(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(x);
@@ -116,9 +119,7 @@ MGP_HD double mgp_sqrt_pos(double x) {
   const double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
-  double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
+  const double d = __builtin_fma(-g, g, x);
   return __builtin_fma(d, h, g);
 #else
   return __builtin_sqrt(x);
