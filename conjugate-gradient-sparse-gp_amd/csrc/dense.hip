@@ -380,18 +380,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ P
       // past the last step the request is a dummy: the current step again, or (UA: it may be the partial one) step 0
       const long kn = (k0 + BK < K ? k0 + BK : (UA ? 0 : k0)) + skk;
       const bool part_next = UA && (k0 + BK < K) && (k0 + 2 * BK > K);  // uniform: the step being requested is the partial one
+      // operand fragments: lane group g takes k = 4g .. 4g+3 of the 16-wide step (MFMA j contracts k = 4g + j over the
+      // four groups) -- four consecutive elements per tile, read as 16-byte LDS loads, instead of k = ks + g, one
+      // element per MFMA (half the LDS instructions, no 2-way conflicts of the compiler's ds_read2_b64 pairing)
+      T afa[WT][4], bfa[WT][4];
+#pragma unroll
+      for (int mi = 0; mi < WT; ++mi)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          afa[mi][x] = Ps[(wm * 16 * WT + mi * 16 + (lane & 15)) * LDS_S + 4 * (lane >> 4) + x];
+#pragma unroll
+      for (int q = 0; q < WT; ++q)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          bfa[q][x] = As[(wn * 16 * WT + q * 16 + (lane & 15)) * LDS_S + 4 * (lane >> 4) + x];
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 4) {
-        T af[WT], bf[WT];
-#pragma unroll
-        for (int mi = 0; mi < WT; ++mi)
-          af[mi] = Ps[(wm * 16 * WT + mi * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
-#pragma unroll
-        for (int q = 0; q < WT; ++q) bf[q] = As[(wn * 16 * WT + q * 16 + (lane & 15)) * LDS_S + ks + (lane >> 4)];
 #pragma unroll
         for (int mi = 0; mi < WT; ++mi)
 #pragma unroll
-          for (int q = 0; q < WT; ++q) acc[mi][q] = Mfma<T>::run(af[mi], bf[q], acc[mi][q]);
+          for (int q = 0; q < WT; ++q) acc[mi][q] = Mfma<T>::run(afa[mi][ks / 4], bfa[q][ks / 4], acc[mi][q]);
         constexpr int G = (NL + 3) / 4;  // loads per operand behind this group
 #pragma unroll
         for (int u = (ks / 4) * G; u < (ks / 4 + 1) * G && u < NL; ++u) {
