@@ -59,7 +59,11 @@ struct mgp_handle {
   // offset at D <= 16; 0 = the LDS-tile kernel it replaced (MGP_SWEEP_FAST, for A/B runs)
   int sweep_fast = 2;
   int pf_trips = 16, pf_ahead = 6144;  // L2 prefetch of streamed rows: every pf_trips loop trips (power of two), pf_ahead bytes on
-  int sweep_target_per_cu = 8;  // chunking of the streamed set aims at this many 256-thread workgroups per CU (MGP_SWEEP_TARGET)
+  // chunking of the streamed set aims at this many 256-thread workgroups per CU (MGP_SWEEP_TARGET).  16 since the
+  // per-workgroup timeline of round 2: the two workgroups of a CU do not share it, the older one runs at full speed
+  // and the younger fills its stalls, so each CU ends with one workgroup running alone at ~0.82 of the rate of two --
+  // the shorter the workgroups, the shorter that tail (C3: 4.75 -> 4.66 ms per CG step against 8)
+  int sweep_target_per_cu = 16;
   int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
   int sweep_fast_rpt_rc = 2;  // owned points per lane with 2 or 4 right-hand sides at D <= 8 (2 or 3) -- MGP_SWEEP_RPT_RC
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
