@@ -53,8 +53,7 @@ def knm_matvec(spec, X, Z, V, v_layout=COLS, out_layout=None):
     out = torch.empty((N, R) if out_layout == COLS else (R, N), dtype=X.dtype, device=X.device)
     if N == 0 or R == 0:
         return out
-    if M == 0:
-        return out.zero_()
+    # M == 0 (empty inducing set) goes through the C-ABI too: libmgp writes the zeros
     hd = _hip.get_handle(X.device)
     k = spec.struct(_hip.dtype_code(X))
     hd.check(hd.lib.mgp_knm_matvec(hd.h, ctypes.byref(k), _hip.ptr(X), N, _hip.ptr(Z), M, _hip.ptr(V), R,
@@ -77,8 +76,7 @@ def kmn_matvec(spec, X, Z, W, w_layout=COLS, out_layout=None):
     out = torch.empty((M, R) if out_layout == COLS else (R, M), dtype=X.dtype, device=X.device)
     if M == 0 or R == 0:
         return out
-    if N == 0:
-        return out.zero_()
+    # N == 0 (a rank without rows) goes through the C-ABI too: libmgp writes the zeros
     hd = _hip.get_handle(X.device)
     k = spec.struct(_hip.dtype_code(X))
     hd.check(hd.lib.mgp_kmn_matvec(hd.h, ctypes.byref(k), _hip.ptr(X), N, _hip.ptr(Z), M, _hip.ptr(W), R,

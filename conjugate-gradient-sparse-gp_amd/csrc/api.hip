@@ -50,6 +50,10 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (skd && strcmp(skd, "0") == 0) h->skinny_defer = 0;
   const char* skp = getenv("MGP_SKINNY_PIPE");
   if (skp && strcmp(skp, "0") == 0) h->skinny_pipe = 0;
+  const char* tf = getenv("MGP_TRI_FORM");
+  if (tf) h->tri_form = atoi(tf);
+  const char* cd1 = getenv("MGP_CG_DENSE1");
+  if (cd1) h->cg_dense1 = atoi(cd1);
   const char* tm = getenv("MGP_TRI_MIN_N");
   if (tm && atol(tm) > 0) h->tri_min_n = atol(tm);
   const char* ns = getenv("MGP_NOSPLIT_PER_CU");
@@ -101,7 +105,8 @@ extern "C" size_t mgp_workspace_bytes(const mgp_handle* h) {
   if (!h) return 0;
   if (h->pool) return h->pool_used;
   // 256 bytes of alignment slack per arena, as a fixed pool would spend
-  return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + h->pack[0].bytes + h->pack[1].bytes + 6 * 256;
+  return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + h->pack[0].bytes + h->pack[1].bytes +
+         h->tri_tab_bytes + 7 * 256;
 }
 
 extern "C" int mgp_destroy(mgp_handle* h) {
@@ -114,6 +119,7 @@ extern "C" int mgp_destroy(mgp_handle* h) {
     if (h->cg) (void)hipFree(h->cg);
     if (h->opws) (void)hipFree(h->opws);
     if (h->gen) (void)hipFree(h->gen);
+    if (h->tri_tab) (void)hipFree(h->tri_tab);
     for (auto& ps : h->pack)
       if (ps.buf) (void)hipFree(ps.buf);
   }

@@ -20,12 +20,7 @@
 
 namespace {
 
-struct CgCtrl {
-  int active;
-  int iters;
-  unsigned ticket;  // arrivals of the fused update kernel's workgroups (reset by the last one)
-  int pad;
-};
+using CgCtrl = MgpCgCtrl;  // mgp_common.h (shared with cg_dense1.hip)
 
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* red) {
@@ -505,7 +500,12 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   const bool need_z = pc.kind != MGP_PRE_EYE && cb == nullptr;   // dense: z = r @ Pinv lives in the arena
   if (dense_pre) pc.kind = MGP_PRE_EYE;                          // the update kernels never apply it themselves
   // arena: r, p, ap, [z], rz[Bt], over[Bt] (int), ctrl
-  size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64;
+  // one right-hand side on a dense matrix, no residual refresh inside the solve: the two-launch iteration of
+  // cg_dense1.hip (tile shares, chunk shares, two direction buffers live behind the control word)
+  const bool dense1 = op->kind == MGP_OP_DENSE && Bt == 1 && !dense_pre && pc.kind != MGP_PRE_BLOCK && cycle > max_it &&
+                      mgp_dense1_eligible(h, n);
+  size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64 +
+                 (dense1 ? mgp_dense1_bytes(op->dtype, n) : 0);
   MGP_TRY(mgp_reserve(h, &h->cg, &h->cg_bytes, bytes));
   T* r = (T*)h->cg;
   T* p = r + tot;
@@ -514,6 +514,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   T* rz = (need_z ? ap + tot : ap) + tot;
   int* over = (int*)(rz + Bt);
   CgCtrl* ctrl = (CgCtrl*)(((uintptr_t)(over + Bt) + 15) & ~(uintptr_t)15);
+  void* d1_arena = (void*)(((uintptr_t)(ctrl + 1) + 15) & ~(uintptr_t)15);
   hipStream_t s = h->stream;
   // z = M^-1 r for the preconditioners applied outside the update kernels
   auto external_z = [&](const int* gate) -> int {
@@ -535,7 +536,12 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   } else {
     MGP_HIP(h, hipMemsetAsync(V, 0, (size_t)tot * sizeof(T), s));
   }
-  if (!dense_pre) {
+  MgpDense1 d1;
+  if (dense1) {
+    MGP_TRY(mgp_dense1_begin(h, &d1, op->dtype, op->A, n, B, av, V, r,
+                             pc.kind == MGP_PRE_JACOBI ? pc.diag_inv : nullptr, ctrl, d1_arena, thr, min_float, max_it));
+    MGP_TRY(mgp_dense1_finish(h, &d1, rz, err_out, over));  // statistics of r_0 and the first gate
+  } else if (!dense_pre) {
     hipLaunchKernelGGL((cg_init_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, B, av, r, z, p, rz, over, err_out,
                        n, (T)thr, pc);
     MGP_LAUNCH_CHECK(h);
@@ -547,8 +553,10 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
                        err_out, n, (T)thr, (T)min_float, pc, 5, 1);
     MGP_LAUNCH_CHECK(h);
   }
-  hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 0, (int)max_it);
-  MGP_LAUNCH_CHECK(h);
+  if (!dense1) {
+    hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(256), 0, s, ctrl, over, Bt, 0, (int)max_it);
+    MGP_LAUNCH_CHECK(h);
+  }
 
   // fused step kernel: elements of one RHS in registers.  Code = EPT for 256 threads (n <= 1024),
   // 14/12/24/8 for 1024 threads with EPT 1/2/4/8 (n <= 8192); 0 = generic loop kernels.
@@ -571,6 +579,11 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     if (!host.active || enq >= max_it) break;
     long batch = check_every;
     if (enq + batch > max_it) batch = max_it - enq;
+    if (dense1) {
+      for (long q = 0; q < batch; ++q, ++enq) MGP_TRY(mgp_dense1_step(h, &d1, enq + 1));
+      MGP_TRY(mgp_dense1_finish(h, &d1, rz, err_out, over));
+      continue;
+    }
     for (long q = 0; q < batch; ++q, ++enq) {
       const bool reset = (enq % cycle) == (cycle - 1);  // :71 (enq == state.i while active)
       // dense operator + fused update: the skinny product may leave its slices for the update to add

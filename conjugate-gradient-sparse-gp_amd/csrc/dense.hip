@@ -224,6 +224,87 @@ __global__ __launch_bounds__(256) void symm_gemv_tri_kernel(const T* __restrict_
   }
 }
 
+// One step of the reduce-scatter over lanes: lanes whose BIT is set keep the upper HALF of the values they carry,
+// the others the lower; each adds its partner's copy of what it keeps.  (Template constants: with run-time loop
+// bounds the compiler indexed x[] dynamically -- 859 v_cndmask in the first version of this kernel.)
+template <typename T, int HALF, int BIT>
+__device__ __forceinline__ void lane_reduce_scatter_step(T (&x)[16], int l) {
+  const bool hi = (l & BIT) != 0;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const T keep = hi ? x[k + HALF] : x[k];
+    const T send = hi ? x[k] : x[k + HALF];
+    x[k] = keep + __shfl_xor(send, BIT, 64);
+  }
+}
+
+// (I, J) of every upper-triangle tile in launch order, built once per nt (the sqrt + correction loops that round 1s
+// kernel runs per workgroup are ~300 scalar instructions in front of its first load)
+__global__ void tri_tile_table_kernel(int2* __restrict__ tab, int nt) {
+  const int I = blockIdx.x;
+  const long start = (long)I * nt - (long)I * (I - 1) / 2;
+  for (int J = I + threadIdx.x; J < nt; J += blockDim.x) tab[start + (J - I)] = make_int2(I, J);
+}
+
+// Round 3 form of the tile kernel.  Same tiles, same slots, but the 64 row sums of a tile no longer go through a
+// 33 KB LDS staging array: a wave holds 16 rows x 64 columns of products, one row-value per lane and row, and a
+// reduce-scatter over the lanes (xor 32, 16, 8, 4: each step halves the rows a lane still carries; then xor 2, 1)
+// leaves lane l with the total of row l >> 2 -- 17 64-bit cross-lane moves per wave instead of 16 LDS stores, a
+// barrier and 16 LDS loads per lane.  One code path for whole and ragged tiles: addresses are clamped to the last
+// row / column and the strays zeroed by selects (a guarded load is a branch; at the join of a guarded and an
+// unguarded path the compiler's wait counts are the pessimistic merge of both).  n = 4096: 14.0 -> 12.6 us.
+// A two-tiles-per-workgroup variant (1 KB per row and request) measured slower (17.2 us) and was removed.
+template <typename T>
+__global__ __launch_bounds__(256) void symm_gemv_tri_bfly_kernel(const T* __restrict__ A, long n,
+                                                                 const T* __restrict__ p, T* __restrict__ Q,
+                                                                 const int2* __restrict__ tab,
+                                                                 const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  constexpr int TS = 64;
+  __shared__ T colp[4][TS];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int2 ij = tab[blockIdx.x];  // uniform: a scalar load
+  const int I = ij.x, J = ij.y;
+  const long r0 = (long)I * TS + 16 * w, c = (long)J * TS + l, ci = (long)I * TS + l;
+  const long cj = c < n ? c : n - 1, cic = ci < n ? ci : n - 1;
+  const T pj_raw = p[cj], pi_raw = p[cic];
+  T a[16];
+  {
+    const T* row = A + (r0 < n ? r0 : n - 1) * n + cj;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      a[q] = *row;
+      row += (r0 + q + 1 < n) ? n : 0;
+    }
+  }
+  const T pj = c < n ? pj_raw : (T)0, pi = ci < n ? pi_raw : (T)0;
+  T x[16];
+  T cs = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const T aq = (r0 + q < n && c < n) ? a[q] : (T)0;
+    x[q] = aq * pj;
+    cs = mgp_fma(aq, mgp_read_lane(pi, 16 * w + q), cs);
+  }
+  colp[w][l] = cs;
+  lane_reduce_scatter_step<T, 8, 32>(x, l);
+  lane_reduce_scatter_step<T, 4, 16>(x, l);
+  lane_reduce_scatter_step<T, 2, 8>(x, l);
+  lane_reduce_scatter_step<T, 1, 4>(x, l);
+  T s = x[0];
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  const long i = r0 + (l >> 2);
+  if ((l & 3) == 0 && i < n) Q[(long)J * n + i] = s;
+  __syncthreads();
+  if (t < TS && I != J) {
+    const T sc = (colp[0][t] + colp[1][t]) + (colp[2][t] + colp[3][t]);
+    const long i2 = (long)J * TS + t;
+    if (i2 < n) Q[(long)I * n + i2] = sc;
+  }
+}
+
 // out[i] = sum_k Q[k][i], k ascending in four fixed runs per row
 template <typename T>
 __global__ __launch_bounds__(256) void symm_gemv_tri_reduce_kernel(const T* __restrict__ Q, long n, int nt,
@@ -1165,6 +1246,38 @@ int symm_skinny_lds_launch(mgp_handle* h, const T* A, long n, const T* P, long B
   return MGP_OK;
 }
 
+// slots Q[nt][n] in h->ws and the tile table of the one-RHS upper-triangle product
+int tri_prepare(mgp_handle* h, size_t esize, long n, int form) {
+  const int nt = (int)((n + 63) / 64);
+  MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nt * n * esize));
+  if (form != 0 && h->tri_tab_nt != nt) {
+    const long ntiles = (long)nt * (nt + 1) / 2;
+    MGP_TRY(mgp_reserve(h, &h->tri_tab, &h->tri_tab_bytes, (size_t)ntiles * sizeof(int2)));
+    hipLaunchKernelGGL(tri_tile_table_kernel, dim3((unsigned)nt), dim3(64), 0, h->stream, (int2*)h->tri_tab, nt);
+    MGP_LAUNCH_CHECK(h);
+    h->tri_tab_nt = nt;
+  }
+  return MGP_OK;
+}
+
+// the tile kernel of the one-RHS upper-triangle product: slots Q[nt][n] left in h->ws
+template <typename T>
+int symm_gemv_tri_slots_t(mgp_handle* h, const T* A, long n, const T* P, const int* gate, int* nt_out) {
+  const int nt = (int)((n + 63) / 64);
+  const long ntiles = (long)nt * (nt + 1) / 2;
+  const int form = nt <= 512 ? h->tri_form : 0;  // the tile table is kept for n <= 32768 (1 MB)
+  MGP_TRY(tri_prepare(h, sizeof(T), n, form));
+  if (form != 0)
+    hipLaunchKernelGGL((symm_gemv_tri_bfly_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, A, n, P,
+                       (T*)h->ws, (const int2*)h->tri_tab, gate);
+  else
+    hipLaunchKernelGGL((symm_gemv_tri_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, A, n, P,
+                       (T*)h->ws, nt, gate);
+  MGP_LAUNCH_CHECK(h);
+  *nt_out = nt;
+  return MGP_OK;
+}
+
 template <typename T>
 int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out, const int* gate) {
   if (Bt >= 2 && Bt <= 128) {
@@ -1197,12 +1310,8 @@ int symm_matmul_t(mgp_handle* h, const T* A, long n, const T* P, long Bt, T* out
     return gemm_nt_launch<T>(h, P, n, Bt, A, n, n, n, out, n, 0, gate);
   }
   if (n >= h->tri_min_n && n <= 64L * 32768) {
-    const int nt = (int)((n + 63) / 64);
-    MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, (size_t)nt * n * sizeof(T)));
-    const long ntiles = (long)nt * (nt + 1) / 2;
-    hipLaunchKernelGGL((symm_gemv_tri_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, h->stream, A, n, P,
-                       (T*)h->ws, nt, gate);
-    MGP_LAUNCH_CHECK(h);
+    int nt = 0;
+    MGP_TRY(symm_gemv_tri_slots_t<T>(h, A, n, P, gate, &nt));
     hipLaunchKernelGGL((symm_gemv_tri_reduce_kernel<T>), dim3((unsigned)nt), dim3(256), 0, h->stream,
                        (const T*)h->ws, n, nt, out, gate);
     MGP_LAUNCH_CHECK(h);
@@ -1244,6 +1353,13 @@ int symm_gemv_rows_t(mgp_handle* h, const T* A, long n, const T* p, long rb, lon
     hipLaunchKernelGGL((symm_gemv_kernel<T, 1, 1>), grid, dim3(256), 0, h->stream, A, n, p, 1, out, gate, rb, re,
                        alpha, 1);
   MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+int mgp_symm_gemv_tri_prepare(mgp_handle* h, int dtype, int64_t n, void** Q, const void** tab) {
+  MGP_TRY(tri_prepare(h, mgp_elem(dtype), n, 1));
+  *Q = h->ws;
+  *tab = h->tri_tab;
   return MGP_OK;
 }
 

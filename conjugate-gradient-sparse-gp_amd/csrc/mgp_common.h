@@ -74,6 +74,16 @@ struct mgp_handle {
   // one-RHS symmetric product on the upper triangle (dense.hip); sizes below tri_min_n use the
   // row-streaming GEMV (MGP_TRI_MIN_N)
   long tri_min_n = 1024;
+  // form of that product's tile kernel: 1 = row sums by a cross-lane reduce-scatter (2 KB of LDS), 0 = round 1's
+  // LDS-staged row sums (35 KB, four workgroups per CU) -- MGP_TRI_FORM
+  int tri_form = 1;
+  void* tri_tab = nullptr;  // (I, J) of the upper-triangle tiles in launch order, for tri_tab_nt tile rows
+  size_t tri_tab_bytes = 0;
+  int tri_tab_nt = 0;
+  // one-right-hand-side dense CG (the reference's literal loop, conjugate_gradient.py:65-84): 1 = two launches per
+  // iteration with no hand-off inside either (cg_dense1.hip), 0 = product (tile kernel + slot reduce) + fused
+  // update launch (MGP_CG_DENSE1)
+  int cg_dense1 = 1;
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
   int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
   int skinny_stagger = 0;  // experiment (MGP_SKINNY_STAGGER): start-up delay units between workgroup phases
@@ -179,7 +189,47 @@ inline int mgp_reserve(mgp_handle* h, void** p, size_t* have, size_t need) {
   return MGP_OK;
 }
 
+// value of `v` in lane `src` (wave-uniform) as a scalar operand: v_readlane, no LDS-pipe traffic
+__device__ __forceinline__ double mgp_read_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float mgp_read_lane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 int mgp_build_e2tabs(mgp_handle* h);  // sweep.hip
+// dense.hip: slots Q[nt][n] (h->ws) and the (I, J) table of the one-RHS upper-triangle product, nt = ceil(n/64);
+// Q[k][i] = contribution of chunk k to output element i, summed by the caller in k order
+int mgp_symm_gemv_tri_prepare(mgp_handle* h, int dtype, int64_t n, void** Q, const void** tab);
+
+// cg_dense1.hip: one right-hand side on a dense matrix, two launches per iteration
+struct MgpCgCtrl {
+  int active;
+  int iters;
+  unsigned ticket;  // arrivals of the fused update kernel's workgroups (reset by the last one)
+  int pad;
+};
+struct MgpDense1 {
+  int dtype = 0, nt = 0, max_it = 0;
+  int64_t n = 0;
+  long ntiles = 0;
+  const void* A = nullptr;
+  const void* dinv = nullptr;
+  void *V = nullptr, *r = nullptr, *Q = nullptr, *tpart = nullptr, *cpart = nullptr, *scal = nullptr;
+  void* pb[2] = {nullptr, nullptr};
+  const void* tab = nullptr;
+  MgpCgCtrl* ctrl = nullptr;
+  double thr = 0, min_float = 0;
+};
+size_t mgp_dense1_bytes(int dtype, int64_t n);
+bool mgp_dense1_eligible(const mgp_handle* h, int64_t n);
+int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
+                     void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
+                     int64_t max_it);
+int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k);
+int mgp_dense1_finish(mgp_handle* h, const MgpDense1* st, void* rz, void* err, int* over);
 
 inline size_t mgp_elem(int dtype) { return dtype == MGP_F64 ? 8 : 4; }
 

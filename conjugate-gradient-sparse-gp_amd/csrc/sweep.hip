@@ -1071,6 +1071,18 @@ int sweep_kind(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T*
   }
 }
 
+// out(i, r) = alpha * addend(i, r) (or 0): the product over an empty streamed set
+template <typename T>
+__global__ __launch_bounds__(256) void empty_sum_kernel(T* __restrict__ out, long o_si, long o_sr, long na, int R,
+                                                        T alpha, const T* __restrict__ addend, long ad_si, long ad_sr,
+                                                        const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= na * R) return;
+  const long i = e / R, r = e - i * R;
+  out[i * o_si + r * o_sr] = addend != nullptr ? alpha * addend[i * ad_si + r * ad_sr] : (T)0;
+}
+
 }  // namespace
 
 int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
@@ -1080,8 +1092,18 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
   if (na == 0 || R == 0) return MGP_OK;
   if (!A || !out.base || (nb > 0 && (!B || !W.base))) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
   if (nb == 0) {
-    // empty sum: out = alpha*addend (or 0); rare path, handled by a 1-chunk sweep over a dummy tile
-    return mgp_fail(h, MGP_E_SHAPE, "empty broadcast set");
+    // empty sum (no inducing points / no local rows): out = alpha*addend, or zeros -- what the dense product of
+    // the reference gives for a [B,0].[0,R] contraction (models.py:351 with an empty Kmn)
+    const long tot = (long)na * R;
+    const unsigned g = (unsigned)((tot + 255) / 256);
+    if (k->dtype == MGP_F64)
+      hipLaunchKernelGGL((empty_sum_kernel<double>), dim3(g), dim3(256), 0, h->stream, (double*)out.base, out.si,
+                         out.sr, (long)na, R, alpha, (const double*)addend.base, addend.si, addend.sr, gate);
+    else
+      hipLaunchKernelGGL((empty_sum_kernel<float>), dim3(g), dim3(256), 0, h->stream, (float*)out.base, out.si, out.sr,
+                         (long)na, R, (float)alpha, (const float*)addend.base, addend.si, addend.sr, gate);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
   }
   if (k->D > MGP_FUSED_MAX_D) return mgp_sweep_generic(h, k, A, na, B, nb, W, R, out, alpha, addend, gate);
   if (k->dtype == MGP_F64 && h->sweep_mode == 1)

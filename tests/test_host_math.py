@@ -17,8 +17,12 @@ SO = os.path.join(ROOT, "conjugate-gradient-sparse-gp_amd", "cggp", "libmgp_host
 
 @pytest.fixture(scope="module")
 def hm():
-    subprocess.run(["make", "-C", CSRC, "hostmath"], check=True, capture_output=True)
-    lib = ctypes.CDLL(SO)
+    # MGP_HOSTMATH_LIBRARY: the sanitizer run (tests/test_sanitizers.py) points this at the ASan/UBSan build
+    so = os.environ.get("MGP_HOSTMATH_LIBRARY")
+    if not so:
+        subprocess.run(["make", "-C", CSRC, "hostmath"], check=True, capture_output=True)
+        so = SO
+    lib = ctypes.CDLL(so)
     for n in ("mgp_host_exp2", "mgp_host_exp2_tab"):
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
     lib.mgp_host_exp2_shifted.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long]
