@@ -102,6 +102,13 @@ struct mgp_handle {
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
+  // bench-only: shader-clock sampler (mgp_profile_clock_begin / _end), one wave on its own stream
+  hipStream_t clk_stream = nullptr;
+  void* clk_buf = nullptr;
+  size_t clk_bytes = 0;
+  volatile int* clk_stop = nullptr;  // pinned, mapped
+  bool clk_running = false;
+  int clk_cap = 0;
 };
 
 // scope guard of mgp_pcg_solve: packs made during the solve are reused by its later iterations

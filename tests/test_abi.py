@@ -40,7 +40,7 @@ def test_header_symbols_exported_and_typed(lib):
 
 def test_version_arch_and_struct_layout(lib):
     from cggp import _hip
-    assert lib.mgp_version() == _hip.MGP_VERSION == 200
+    assert lib.mgp_version() == _hip.MGP_VERSION == 210
     assert lib.mgp_build_arch() == b"gfx950"
     # struct sizes the C side compiles to (LP64): keeps the ctypes mirror honest
     assert ctypes.sizeof(_hip.MgpKernel) == 4 * 4 + 8 + 8 * _hip.MGP_MAX_D
