@@ -12,9 +12,17 @@ one fused K_nm.p sweep, one fused K_mn.u sweep, the replicated dense Kmm.p produ
 all-reduce of the [1, M] partial (N > 1), and the fused vector update -- all inside libmgp.
 The rows of X are sharded over the ranks (strong scaling: N is the TOTAL row count).
 Inputs are resident in HBM before the timed region.
+
+`roofline` (dominant kernel: the fused sweep, a vector-ALU-issue-bound kernel -- DESIGN.md 4.1).  Every number
+can be recomputed from this line and ONE committed file, profiles/valu_issue_model.json (PMC, per config):
+    busy  = pairs_per_launch / 64 * active_valu_quadcycles_per_wave_pair          [VALU-busy quad-cycles, all SIMDs]
+    frac  = busy * 4 / (1024 SIMDs * 2.4e9 Hz) / avg_launch_s                     [issue-slot fraction, datasheet clock]
+    frac_at_sustained_clock = the same with the shader clock MEASURED inside the timed launches
+                              (mgp_profile_read_clocks: workgroups stamp s_memtime / s_memrealtime at start and end)
 """
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -29,26 +37,26 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet (== fp64 matrix peak); MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R), C_SE = 35
-# ALGORITHMIC flops per pair of the fused SE product, frozen at round 1's count so that rounds
-# compare: distance D fma (2D) + exp2 on a reduced argument (3 add, 2 fma, mul, fma, scale = 11) + R accumulate fma
-# (2R).  The kernel may execute fewer instructions than this (round 2 does); time is what is measured.
-ALG_FLOPS_PER_PAIR = lambda D, R: 2 * D + 11 + 2 * R
-# VALU wave-instructions the current kernels issue per pair, by element size (csrc/sweep.hip, fp64 SE fast
-# kernel: D fma + 3 add + 2 fma + mul + fma + R fma = D + 7 + R fp64 and 2 integer -- PMC: 18.3 per pair at
-# D = 8, R = 1 with the per-point overheads; fp32 SE: D fma + v_exp_f32 + R fma), and the cycles one
-# wave-instruction holds a SIMD (fp64 16 lanes/clk -> 4; fp32 and 32-bit integer 32 lanes/clk -> 2 nominal;
-# profiles/r02_valu_issue_probe.txt: next to fp64 work an integer instruction costs ~0.75 of an fp64 slot)
-# fp32 (C4): D + R fp32 fma slots (v_fma_f32 holds a SIMD 2 cycles per wave, v_pk_fma_f32 4 cycles for two pairs) and one
-# v_exp_f32, which holds it 8 cycles -- tools/micro/valu_issue.hip, profiles/r02_valu_issue_probe_fp32.txt: 16 fma32
-# 9.8 ms, 16 pk_fma32 18.1 ms, 16 exp32 34.7 ms against 16 fma64 18.6 ms; mixes add up, nothing overlaps.  The second
-# entry of each pair is "the other kind": 32-bit integer instructions for fp64, the transcendental for fp32.
-VALU_INSTR_PER_PAIR = {8: lambda D, R: (D + 7 + R, 2), 4: lambda D, R: (D + R, 1)}  # (float, other)
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 16 fp64 lanes per SIMD and clock, 2.4 GHz peak engine clock
 NUM_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
-CYCLES_PER_WAVE_INSTR = {8: (4, 2), 4: (2, 8)}  # (float, other) by element size
-FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X datasheet (packed fp32); used when the config computes in fp32 (C4)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz (== the fp64 matrix peak, same ALUs)
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0           # 8.0 TB/s spec (6.29 TB/s measured copy)
+# One VALU wave-instruction of fp64 class holds its SIMD for 4 cycles ("quad-cycle"; SQ_ACTIVE_INST_VALU counts
+# them): the issue peak of the chip is 1024 x 2.4e9 / 4 quad-cycles per second.
+PEAK_GQUAD_PER_S = NUM_SIMDS * MAX_CLOCK_HZ / 4 / 1e9
+# flops the kernels EXECUTE per pair, from their instruction lists (csrc/sweep.hip), by (element size, kernel):
+#   fp64 SE (fast kernel): D fma + 3 add (magic) + 2 fma + mul + fma (table) + R fma (accumulate) = 2D + 10 + 2R
+#   fp64 Matern-3/2: the same + rsq/Goldschmidt sqrt (8 instr, 14 flop) + polynomial fma + mul = 2D + 27 + 2R (approx.)
+#   fp32 SE (LDS-tile kernel, v_exp_f32 counted as ONE flop): D fma + exp + R fma = 2D + 1 + 2R
+EXECUTED_FLOPS_PER_PAIR = {(8, "se"): lambda D, R: 2 * D + 10 + 2 * R, (8, "matern32"): lambda D, R: 2 * D + 27 + 2 * R,
+                           (4, "se"): lambda D, R: 2 * D + 1 + 2 * R}
+SURVEY_FLOPS_PER_PAIR = lambda D, R: 3 * D + 35 + 2 * R  # N M (3D + C_SE + 2R) -- a libm-exp MODEL
+
+
+def _pct(a):
+    a = np.asarray(a, dtype=np.float64)
+    return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90))}
 
 
 def main():
@@ -64,6 +72,11 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1 only: run the all-reduce hook on a 1-rank group (measures its fixed per-step cost)")
     ap.add_argument("--rows", type=int, default=0, help="override the TOTAL row count (0 = the config's)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="N=1 only: what ONE rank of a W-GPU run does per step -- N/W rows, the 1/W row slab of the "
+                         "replicated Kmm.p term, the collective on a 1-rank communicator.  Timing only: the operator is "
+                         "a rank's PARTIAL, so the legs that need the whole system are skipped")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the convergence / CDGP / CPU legs")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default): the config's N is the TOTAL row count, sharded over the ranks -- the "
                          "size BASELINE.json's metric is quoted on; weak: every rank holds the config's N rows")
@@ -81,6 +94,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    emu = args.emulate_world if world == 1 else 0
+    if emu:
+        args.force_collective = True
+        args.no_extra_legs = True
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
@@ -99,11 +116,13 @@ def main():
     from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
 
     N, D, M, dtype_name, kname = synthetic.CONFIGS[args.config]
+    N_config = N
     if args.rows:
         N = args.rows
+    if emu:
+        N = N // emu
     if args.scaling == "weak":
         N = N * world  # per-GPU work fixed: the job grows with the number of ranks
-    tdtype = torch.float64 if dtype_name == "float64" else torch.float32
     esize = 8 if dtype_name == "float64" else 4
     syn = synthetic.make_inputs(N, D, M, dtype_name)
     lo, hi = parallel.shard_bounds(N, world, rank)
@@ -115,8 +134,9 @@ def main():
         variance=syn.variance, lengthscales=syn.lengthscales)
     spec = kern.spec(D)
     allreduce = parallel.make_allreduce(force=args.force_collective)
+    kmm_rows = parallel.kmm_slab(M, emu, 0) if emu else parallel.kmm_slab(M)
     op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1,
-                            kmm_rows=parallel.kmm_slab(M))
+                            kmm_rows=kmm_rows)
     rhs = ops.kmn_matvec(spec, X, Z, y)  # K_mn y  [M,1]
     if allreduce is not None:
         allreduce(rhs.view(-1))
@@ -148,44 +168,100 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- dominant kernel: the fused sweep (K_nm.p and K_mn.u are the same kernel symbol),
-    # HIP events bracketing every launch of it over a second pass of the same K steps
+    # ---- dominant kernel: the fused sweep (K_nm.p and K_mn.u are the same kernel symbol).  A second pass of the
+    # same K steps with HIP events bracketing every launch of it on the solve's stream, while one resident wave
+    # samples the shader clock (started first, so that it holds its slot before the sweeps fill the chip)
     hd = _hip.get_handle(dev)
+    clock = None
     hd.check(hd.lib.mgp_profile_enable(hd.h, 1))
     run_steps(args.steps)
-    import ctypes
     launches = ctypes.c_int64(0)
     each = (ctypes.c_double * (2 * args.steps + 8))()
     hd.check(hd.lib.mgp_profile_read_each(hd.h, each, len(each), ctypes.byref(launches)))
+    cap = 16 * (2 * args.steps + 8)
+    mhz = (ctypes.c_double * cap)()
+    nclk = ctypes.c_int64(0)
+    if hd.lib.mgp_profile_read_clocks(hd.h, mhz, cap, ctypes.byref(nclk)) == 0 and nclk.value > 0:
+        c = np.array(mhz[:min(nclk.value, cap)], dtype=np.float64)
+        clock = {"mean_mhz": float(c.mean()), **{k + "_mhz": v for k, v in _pct(c).items()},
+                 "min_mhz": float(c.min()), "max_mhz": float(c.max()), "workgroups_sampled": int(nclk.value),
+                 "method": "up to 16 workgroups of every timed sweep launch stamp s_memrealtime (100 MHz) and s_memtime "
+                           "(shader clock) at their start and at the end of their loop; clock = ratio of the differences "
+                           "(mgp_profile_read_clocks)"}
     hd.check(hd.lib.mgp_profile_enable(hd.h, 0))
     durs = np.array(each[:min(launches.value, len(each))], dtype=np.float64)
     sweep_ms = float(durs.mean()) if durs.size else float("nan")
-    sweep_pct = {"median_ms": float(np.median(durs)), "p10_ms": float(np.percentile(durs, 10)),
-                 "p90_ms": float(np.percentile(durs, 90))} if durs.size else None
+    sweep_pct = {k + "_ms": v for k, v in _pct(durs).items()} if durs.size else None
     R = 1
     pairs_launch = float(n_local) * M
-    flops_launch = pairs_launch * ALG_FLOPS_PER_PAIR(D, R)
-    n_fl, n_int = VALU_INSTR_PER_PAIR[esize](D, R)
-    c_fl, c_int = CYCLES_PER_WAVE_INSTR[esize]
-    issue_s = (pairs_launch / 64.0) * (n_fl * c_fl + n_int * c_int) / (NUM_SIMDS * MAX_CLOCK_HZ)
     bytes_launch = float(esize) * (n_local * D + M * D + M * R + n_local * R)
-    ach_tflops = flops_launch / (sweep_ms * 1e-3) / 1e12
-    vector_peak = FP64_VECTOR_PEAK_TFLOPS if esize == 8 else FP32_VECTOR_PEAK_TFLOPS
-    flop_model_exact = kname == "se"
     ach_gbps = bytes_launch / (sweep_ms * 1e-3) / 1e9
     equiv_gemv_gbps = float(esize) * n_local * M / (sweep_ms * 1e-3) / 1e9
+    vector_peak = FP64_VECTOR_PEAK_TFLOPS if esize == 8 else FP32_VECTOR_PEAK_TFLOPS
+    flops_pair = EXECUTED_FLOPS_PER_PAIR.get((esize, kname), EXECUTED_FLOPS_PER_PAIR[(esize, "se")])(D, R)
+    tflops_exec = pairs_launch * flops_pair / (sweep_ms * 1e-3) / 1e12
 
+    # PMC model of this config's kernel instantiation (committed; tools/make_valu_model.py builds it from the
+    # rocprofv3 --pmc passes of tools/pmc_sweep.sh)
+    model, model_src = None, os.path.join("profiles", "valu_issue_model.json")
+    try:
+        model = json.load(open(os.path.join(ROOT, model_src)))["configs"].get(args.config)
+    except Exception:
+        model = None
+    roof = {"bound": "valu",
+            "bound_note": "vector-ALU issue roofline: the kernel issues no MFMA (on MI355X the fp64 matrix and vector "
+                          "peaks are the same ALUs: measured and rejected, DESIGN.md 4.1) and is not HBM-bound (SURVEY 8d); "
+                          "the hbm figures BASELINE.json asks for are in the nested object",
+            "kernel": (f"sweep_fast_kernel<{D},{kname},RC=1,RPT=4,512 threads,2^13-entry table>" if esize == 8 and D <= 8
+                       else f"sweep_fast_kernel<{D},{kname},RC=1>" if esize == 8
+                       else f"sweep_kernel<float,{D},{kname},1>") + " (K_nm.p and K_mn.u are the same symbol)",
+            "unit": "G VALU quad-cycles/s", "peak": PEAK_GQUAD_PER_S,
+            "peak_note": "1024 SIMDs x 2.4e9 Hz / 4: one fp64-class VALU wave-instruction holds its SIMD for 4 cycles "
+                         "(SQ_ACTIVE_INST_VALU counts these quad-cycles; fp32 transcendentals count 2)"}
+    if model:
+        q = float(model["active_valu_quadcycles_per_wave_pair"])
+        busy = pairs_launch / 64.0 * q
+        roof["achieved"] = busy / (sweep_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / PEAK_GQUAD_PER_S
+        roof["model"] = {"file": model_src, "config": args.config,
+                         "active_valu_quadcycles_per_wave_pair": q,
+                         "valu_instructions_per_pair": model.get("valu_instructions_per_pair"),
+                         "pmc_source": model.get("source"), "kernel": model.get("kernel"),
+                         "recompute": "frac = pairs_per_launch / 64 * active_valu_quadcycles_per_wave_pair * 4 / "
+                                      "(1024 * 2.4e9) / (avg_launch_ms * 1e-3)"}
+        if clock:
+            roof["frac_at_sustained_clock"] = busy * 4.0 / (NUM_SIMDS * clock["mean_mhz"] * 1e6) / (sweep_ms * 1e-3)
+    else:
+        roof["achieved"] = None
+        roof["frac"] = None
+        roof["model"] = {"error": f"no entry for {args.config} in {model_src}"}
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{args.config}/gpus{world}", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if model and model.get("hbm_bytes_per_launch") and not args.rows and not emu and world == 1:
+        traffic = float(model["hbm_bytes_per_launch"])
+    roof.update({
+        "sustained_clock": clock,
+        "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value), "launch_percentiles": sweep_pct,
+        "pairs_per_launch": pairs_launch, "gpair_evals_per_s": pairs_launch / (sweep_ms * 1e-3) / 1e9,
+        "traffic": traffic,
+        "traffic_note": "HBM bytes per launch from PMC (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction, separate --pmc "
+                        "passes), mean of the K_nm and K_mn launches; null for row counts the PMC passes did not run",
+        "flops": {"note": "secondary: flops the kernel EXECUTES per pair (instruction list, csrc/sweep.hip) over the "
+                          "vector peak of its dtype; <= the issue fraction because adds/muls/integer ops fill a slot with "
+                          "one flop or none", "executed_flop_per_pair": flops_pair, "tflops": tflops_exec,
+                  "peak_tflops": vector_peak, "frac": tflops_exec / vector_peak,
+                  "survey_model_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
+                  "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
+                                               / vector_peak,
+                  "survey_note": "SURVEY 8d prices a 20-instruction libm exp the kernel does not execute: a model, "
+                                 "not a bound (it exceeds 1)"},
+        "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_launch,
+                "equiv_dense_gemv_GBps_derived": equiv_gemv_gbps}})
 
+    extra = not args.no_extra_legs
     # ---- bounded convergence report (informational): real stopping rule, thr = 1e-6
     conv = None
-    if rank == 0 or world > 1:
+    if extra and (rank == 0 or world > 1):
         cap = args.convergence_cap or M  # reference default cap: max_iterations = n (conjugate_gradient.py:190-192)
         tc = time.perf_counter()
         sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, max_iterations=cap, max_steps_cycle=cap + 1,
@@ -201,88 +277,132 @@ def main():
                 "note": "absolute criterion 0.5||r||^2 <= 1e-6 of the reference, no preconditioner"}
 
     # ---- the same solve with the subsampled normal-equation preconditioner (build-side addition,
-    # DESIGN.md 4.6): P = s2 Kmm + (N/n_s) Ks^T Ks from n_s = 16 M sampled rows, z = r @ P^-1
+    # DESIGN.md 4.3b): P = s2 Kmm + (N/n_s) Ks^T Ks from n_s = 32 M sampled rows, z = r @ P^-1
     pcg = None
-    try:
-        from cggp.conjugate_gradient import SubsampledNormalPreconditioner
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
-        torch.cuda.synchronize()
-        t_build_cold = time.perf_counter() - tb  # includes the one-off load of the factorisation library
-        tb = time.perf_counter()
-        pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
-        torch.cuda.synchronize()
-        t_build = time.perf_counter() - tb
-        tc = time.perf_counter()
-        pcap = min(M, 256)
-        # fp32: the recurrence residual drifts from the true one within ~16 preconditioned steps, so
-        # use the reference's residual refresh (max_steps_cycle, conjugate_gradient.py:71-84) every 4
-        pcycle = pcap + 1 if esize == 8 else 4
-        sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, pre, max_iterations=pcap,
-                                               max_steps_cycle=pcycle, check_every=8)
-        torch.cuda.synchronize()
-        t_solve = time.perf_counter() - tc
-        rres = rhs_rows - op.rmatmul(sol)
-        pcg = {"preconditioner": "SubsampledNormalPreconditioner(rows_per_inducing=32)",
-               "sample_rows": pre.sample_rows, "build_seconds": t_build, "build_seconds_first_call": t_build_cold,
-               "error_threshold": 1e-6,
-               "iteration_cap": pcap, "max_steps_cycle": pcycle, "iterations": int(steps), "converged": bool(int(steps) < pcap),
-               "solve_seconds": t_solve,
-               "half_rz_final": float(err.max().item()),
-               "true_half_residual_sq": 0.5 * float((rres * rres).sum().item())}
-    except Exception as e:
-        if world > 1:
-            raise  # the leg contains collectives: a rank must not drop out of them silently
-        pcg = {"error": repr(e)}
+    if extra:
+        try:
+            from cggp.conjugate_gradient import SubsampledNormalPreconditioner
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
+            torch.cuda.synchronize()
+            t_build_cold = time.perf_counter() - tb  # includes the one-off load of the factorisation library
+            tb = time.perf_counter()
+            pre = SubsampledNormalPreconditioner(op, rows_per_inducing=32, seed=0)
+            torch.cuda.synchronize()
+            t_build = time.perf_counter() - tb
+            tc = time.perf_counter()
+            pcap = min(M, 256)
+            # fp32: the recurrence residual drifts from the true one within ~16 preconditioned steps, so
+            # use the reference's residual refresh (max_steps_cycle, conjugate_gradient.py:71-84) every 4
+            pcycle = pcap + 1 if esize == 8 else 4
+            sol, (steps, err) = conjugate_gradient(op, rhs_rows, None, 1e-6, pre, max_iterations=pcap,
+                                                   max_steps_cycle=pcycle, check_every=8)
+            torch.cuda.synchronize()
+            t_solve = time.perf_counter() - tc
+            rres = rhs_rows - op.rmatmul(sol)
+            pcg = {"preconditioner": "SubsampledNormalPreconditioner(rows_per_inducing=32)",
+                   "sample_rows": pre.sample_rows, "build_seconds": t_build, "build_seconds_first_call": t_build_cold,
+                   "error_threshold": 1e-6,
+                   "iteration_cap": pcap, "max_steps_cycle": pcycle, "iterations": int(steps),
+                   "converged": bool(int(steps) < pcap), "solve_seconds": t_solve,
+                   "half_rz_final": float(err.max().item()),
+                   "true_half_residual_sq": 0.5 * float((rres * rres).sum().item())}
+        except Exception as e:
+            if world > 1:
+                raise  # the leg contains collectives: a rank must not drop out of them silently
+            pcg = {"error": repr(e)}
 
     # ---- CDGP leg at the same size (informational; SURVEY §8e: no per-iteration collective):
     # assignment + cluster statistics over the local rows, one [2,M] all-reduce, then the M x M
-    # system (Kmm + Lambda) a = u solved by the device CG with the reference's stopping rule
+    # system (Kmm + Lambda) a = u solved by the device CG with the reference's stopping rule -- the reference's
+    # literal hot loop (conjugate_gradient.py:65) -- and the predictive mean AND variance of every local row
     cdgp = None
-    try:
-        from cggp.conjugate_gradient import ConjugateGradient
-        from cggp.optimize import nearest_centre_statistics
+    if extra:
+        try:
+            from cggp.conjugate_gradient import ConjugateGradient
+            from cggp.optimize import nearest_centre_statistics
 
-        def timed(fn):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r = fn()
-            torch.cuda.synchronize()
-            return r, 1e3 * (time.perf_counter() - t)
+            def timed(fn):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r = fn()
+                torch.cuda.synchronize()
+                return r, 1e3 * (time.perf_counter() - t)
 
-        (_, _, _), t_assign_first = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
-        (_, sums, counts), t_assign = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
-        counts = torch.where(counts != 0, counts, torch.ones_like(counts))
-        u = (sums / counts)[:, None]
-        _, t_k_first = timed(lambda: kernels.Kuu(Z, kern, jitter=0.0, diag_add=syn.noise_variance / counts))
-        KL, t_k = timed(lambda: kernels.Kuu(Z, kern, jitter=0.0, diag_add=syn.noise_variance / counts))  # warm: the first call pays the M x M allocation
-        cgm = ConjugateGradient(1e-6, check_every=25)
-        (a, (csteps, cerr)), t_cg = timed(lambda: cgm.solve_with_stats(KL, u))
-        res = KL @ a - u
-        (_, t_mean) = timed(lambda: ops.knm_matvec(spec, X, Z, a))
-        # C3's "64 Hutchinson log-det probe vectors": trace estimator of models.py:308-314 and the
-        # log-det-gradient estimator of models.py:37-44, both one 64-RHS CG on (Kmm + Lambda)
-        from cggp.models import CGGP
-        mdl = CGGP(kern, syn.noise_variance, Z, cgm, num_probes=64, pseudo_u=u, cluster_counts=counts[:, None],
-                   num_data=N)
-        probes = torch.from_numpy(synthetic.make_probes(M, 64, dtype_name)).to(dev)
-        (kl, t_kl) = timed(lambda: mdl.prior_kl(probes=probes))
-        (_, t_ldg) = timed(lambda: mdl.logdet_gradient(1.0, probes=probes))
-        cdgp_probe = {"prior_kl_64_probes_ms": t_kl, "prior_kl": kl, "logdet_gradient_64_probes_ms": t_ldg,
-                      "probe_cg_iterations": int(cgm.last_stats[0])}
-        cdgp = {"assign_and_stats_ms": t_assign, "assign_and_stats_first_call_ms": t_assign_first, "kuu_lambda_ms": t_k, "kuu_lambda_first_call_ms": t_k_first,
-                "cg_iterations": int(csteps),
-                "cg_ms": t_cg, "cg_half_rz_final": float(cerr.max().item()),
-                "true_half_residual_sq": 0.5 * float((res * res).sum().item()),
-                "predict_mean_all_local_rows_ms": t_mean, **cdgp_probe}
-    except Exception as e:  # the headline number must not depend on this leg
-        if world > 1:
-            raise  # collectives inside: see above
-        cdgp = {"error": repr(e)}
+            (_, _, _), t_assign_first = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
+            (_, sums, counts), t_assign = timed(lambda: nearest_centre_statistics(kern, Z, (X, y), "sqeuclidean", allreduce))
+            counts = torch.where(counts != 0, counts, torch.ones_like(counts))
+            u = (sums / counts)[:, None]
+            _, t_k_first = timed(lambda: kernels.Kuu(Z, kern, jitter=0.0, diag_add=syn.noise_variance / counts))
+            KL, t_k = timed(lambda: kernels.Kuu(Z, kern, jitter=0.0, diag_add=syn.noise_variance / counts))  # warm: the first call pays the M x M allocation
+            cgm = ConjugateGradient(1e-6, check_every=25)
+            cgm.solve_with_stats(KL, u)  # warm (tile table, arenas)
+            (a, (csteps, cerr)), t_cg = timed(lambda: cgm.solve_with_stats(KL, u))
+            res = KL @ a - u
+            (_, t_mean) = timed(lambda: ops.knm_matvec(spec, X, Z, a))
+            # C3's "64 Hutchinson log-det probe vectors": trace estimator of models.py:308-314 and the
+            # log-det-gradient estimator of models.py:37-44, both one 64-RHS CG on (Kmm + Lambda)
+            from cggp.models import CGGP
+            mdl = CGGP(kern, syn.noise_variance, Z, cgm, num_probes=64, pseudo_u=u, cluster_counts=counts[:, None],
+                       num_data=N)
+            probes = torch.from_numpy(synthetic.make_probes(M, 64, dtype_name)).to(dev)
+            (kl, t_kl) = timed(lambda: mdl.prior_kl(probes=probes))
+            (_, t_ldg) = timed(lambda: mdl.logdet_gradient(1.0, probes=probes))
+            it_us = 1e3 * t_cg / max(int(csteps), 1)
+            tri_bytes = esize * (M * (M + 64) / 2.0)  # the upper triangle's 64 x 64 tiles: what an iteration streams
+            cdgp = {"assign_and_stats_ms": t_assign, "assign_and_stats_first_call_ms": t_assign_first,
+                    "kuu_lambda_ms": t_k, "kuu_lambda_first_call_ms": t_k_first,
+                    "cg_iterations": int(csteps), "cg_ms": t_cg, "cg_us_per_iteration": it_us,
+                    "cg_hbm": {"bytes_per_iteration": tri_bytes, "GBps": tri_bytes / (it_us * 1e-6) / 1e9,
+                               "frac_of_8TBps": tri_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "dense one-RHS CG, two launches per iteration (csrc/cg_dense1.hip); bytes = the "
+                                       "upper-triangle tiles of Kmm+Lambda actually read; includes the solve's start-up "
+                                       "and its polls every 25 iterations"},
+                    "cg_half_rz_final": float(cerr.max().item()),
+                    "true_half_residual_sq": 0.5 * float((res * res).sum().item()),
+                    "predict_mean_all_local_rows_ms": t_mean,
+                    "prior_kl_64_probes_ms": t_kl, "prior_kl": kl, "logdet_gradient_64_probes_ms": t_ldg,
+                    "probe_cg_iterations": int(cgm.last_stats[0])}
+            # predictive VARIANCE of every local row (models.py:340, SURVEY row M3 "dominant cost today"), both ways
+            B = 4096
+            mdl.num_probes = None
+            # (a) build-side option: (Kmm+Lambda) Y = I once (M-column CG to thr^2), then one [B,M].[M,M] GEMM per batch
+            (mv, t_shared) = timed(lambda: mdl.predict_f_batched(X, B, shared_inverse=True))
+            inv_steps = int(mdl.inverse_stats[0])
+            Y = torch.empty((M, M), dtype=X.dtype, device=dev).normal_()
+            Knm = torch.empty((B, M), dtype=X.dtype, device=dev).normal_()
+            ops.symm_matmul(Y, Knm)
+            nb_gemm = 16
+            (_, t_gemm) = timed(lambda: [ops.symm_matmul(Y, Knm) for _ in range(nb_gemm)])
+            gemm_tflops = 2.0 * B * M * M * nb_gemm / (t_gemm * 1e-3) / 1e12
+            # (b) the reference's form: a B-column CG per batch -- on a bounded sample of batches
+            ns = min(n_local, 4 * B)
+            ((mu_b, var_b), t_batch) = timed(lambda: mdl.predict_f_batched(X[:ns], B, shared_inverse=False))
+            batch_steps = int(cgm.last_stats[0])
+            dv = float((mv[1][:ns] - var_b).abs().max().item())
+            cdgp["predict_mean_and_variance_all_local_rows"] = {
+                "rows": n_local, "batch": B,
+                "shared_inverse": {"seconds": t_shared * 1e-3, "inverse_cg_iterations": inv_steps,
+                                   "gemm_flops": 2.0 * n_local * M * M,
+                                   "gemm_tflops_measured_on_this_shape": gemm_tflops,
+                                   "gemm_frac_of_fp64_mfma_peak": gemm_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                   "note": "one M-column CG (threshold^2) + per batch k_dense, [B,M].[M,M] on the matrix "
+                                           "cores, column dots; GEMM rate from 16 calls of the same shape"},
+                "per_batch_cg": {"sample_rows": ns, "seconds_sample": t_batch * 1e-3,
+                                 "seconds_projected_all_rows": t_batch * 1e-3 * n_local / ns,
+                                 "cg_iterations_last_batch": batch_steps,
+                                 "flops_per_iteration": 2.0 * B * M * M,
+                                 "note": "the reference's W = CG(Kmm+Lambda, Kmn) per batch (models.py:340), B = 4096 "
+                                         "columns at threshold 1e-6; timed on the sample, projected linearly"},
+                "max_abs_variance_difference_on_sample": dv}
+        except Exception as e:  # the headline number must not depend on this leg
+            if world > 1:
+                raise  # collectives inside: see above
+            cdgp = {"error": repr(e)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if extra and rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
         ns = min(N, args.cpu_sample_rows)
         sec, threads = cpu_baseline.time_cg_iteration(syn.X[:ns], syn.Z, syn.variance, syn.lengthscales,
@@ -293,10 +413,11 @@ def main():
                          f"chunked K build + GEMV, torch-CPU fp{esize * 8}), {sec:.2f} s, scaled by N/sample"}
 
     if rank == 0:
+        headline = args.config == "C3" and not args.rows and not emu and (args.scaling == "strong" or world == 1)
         out = {
-            "metric": "CG iters/sec (matrix-free SGPR-CG, N=2^20 M=4096 D=8 fp64)"
-                      if args.config == "C3" and not args.rows and (args.scaling == "strong" or world == 1)
-                      else f"CG iters/sec ({args.config}, N={N} total)",
+            "metric": "CG iters/sec (matrix-free SGPR-CG, N=2^20 M=4096 D=8 fp64)" if headline
+                      else (f"CG iters/sec ({args.config}: ONE rank's share of a {emu}-GPU run, {N} of {N_config} rows)"
+                            if emu else f"CG iters/sec ({args.config}, N={N} total)"),
             "value": args.steps / elapsed,
             "unit": "CG iters/s",
             "n_gpus": world,
@@ -310,39 +431,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: CG on S=s2(Kmm+jI)+KmnKnm, K_nm matrix-free, {kname} kernel",
                        "N": N, "D": D, "M": M, "rhs": 1, "rows_per_gpu": n_local,
-                       "parallelism": f"rows of X sharded over {world} GPU(s), one all-reduce of [1,M]+1 per step",
+                       "kmm_rows_of_this_rank": [int(kmm_rows[0]), int(kmm_rows[1])],
+                       "emulated_world": emu or None,
+                       "parallelism": f"rows of X sharded over {emu or world} GPU(s), one all-reduce of [1,M]+1 per step",
                        "collective": ("none (one rank)" if allreduce is None else
                                       "libmgp ncclAllReduce on the solve's stream (mgp_operator.comm)"
                                       if getattr(allreduce, "comm", None) is not None else
                                       "callback hook -> torch.distributed (" + args.backend + ")")},
-            "roofline": {
-                "bound": "valu",
-                "bound_note": "vector-ALU issue roofline: the kernel issues no MFMA (DESIGN.md 4.1: on MI355X the fp64 "
-                              "matrix and vector peaks are the same 78.6 TFLOP/s on the same ALUs, measured and "
-                              "rejected) and is not HBM-bound (SURVEY 8d) -- the hbm figures BASELINE.json asks for "
-                              "are in the nested object",
-                "kernel": (f"sweep_fast_kernel<{D},{kname},RC=1,RPT=4,512 threads,2^13-entry table>"
-                           if esize == 8 and D <= 8 else
-                           f"sweep_fast_kernel<{D},{kname},RC=1>" if esize == 8 else
-                           f"sweep_kernel<{'double' if esize == 8 else 'float'},{D},{kname},1>") +
-                          " (K_nm.p and K_mn.u are the same symbol)",
-                "achieved": ach_tflops, "peak": vector_peak, "unit": "TFLOP/s",
-                "frac": ach_tflops / vector_peak,
-                "flop_model": "algorithmic flops of the fused SE product, DESIGN.md 4.1 (2D + 11 + 2R per pair)"
-                              if flop_model_exact else "the SE count applied to another kernel: approximate",
-                "flop_per_pair": ALG_FLOPS_PER_PAIR(D, R), "pairs_per_launch": pairs_launch,
-                "valu_instr_per_pair": {"float": n_fl, ("int32" if esize == 8 else "transcendental"): n_int},
-                "valu_issue_frac_at_2.4GHz": issue_s / (sweep_ms * 1e-3),
-                "survey_flop_per_pair": SURVEY_FLOPS_PER_PAIR(D, R),
-                "frac_at_survey_flop_count": pairs_launch * SURVEY_FLOPS_PER_PAIR(D, R) / (sweep_ms * 1e-3) / 1e12
-                                             / vector_peak,
-                "avg_launch_ms": sweep_ms, "launches_timed": int(launches.value), "launch_percentiles": sweep_pct,
-                "gpair_evals_per_s": pairs_launch / (sweep_ms * 1e-3) / 1e9,
-                "traffic": traffic,
-                "hbm": {"bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_launch,
-                        "equiv_dense_gemv_GBps_derived": equiv_gemv_gbps},
-            },
+            "roofline": roof,
             "cpu_baseline": cpu,
             # "converging to residual <= 1e-6" (north star): the reference recurrence (identity preconditioner)
             # and the preconditioned one, each with iterations and wall time to the reference's stopping rule

@@ -124,8 +124,7 @@ SIGNATURES = {
     "mgp_profile_enable": (_I, [_P, _I]),
     "mgp_profile_read": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_D)]),
     "mgp_profile_read_each": (_I, [_P, ctypes.POINTER(_D), _L, ctypes.POINTER(_L)]),
-    "mgp_profile_clock_begin": (_I, [_P, _I]),
-    "mgp_profile_clock_end": (_I, [_P, ctypes.POINTER(_D), _L, ctypes.POINTER(_L)]),
+    "mgp_profile_read_clocks": (_I, [_P, ctypes.POINTER(_D), _L, ctypes.POINTER(_L)]),
     # collectives: RCCL communicator ranks
     "mgp_comm_unique_id": (_I, [_P]),
     "mgp_comm_init_rank": (_I, [ctypes.POINTER(_P), _I, _I, _I, _P]),

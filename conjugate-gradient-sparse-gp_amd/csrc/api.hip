@@ -52,6 +52,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (skp && strcmp(skp, "0") == 0) h->skinny_pipe = 0;
   const char* tf = getenv("MGP_TRI_FORM");
   if (tf) h->tri_form = atoi(tf);
+  const char* fa = getenv("MGP_FUSE_AGREE");
+  if (fa) h->fuse_agree = atoi(fa);
   const char* cd1 = getenv("MGP_CG_DENSE1");
   if (cd1) h->cg_dense1 = atoi(cd1);
   const char* tm = getenv("MGP_TRI_MIN_N");
@@ -123,13 +125,7 @@ extern "C" int mgp_destroy(mgp_handle* h) {
     for (auto& ps : h->pack)
       if (ps.buf) (void)hipFree(ps.buf);
   }
-  if (h->clk_running) {
-    *h->clk_stop = 1;
-    (void)hipStreamSynchronize(h->clk_stream);
-  }
-  if (h->clk_buf) (void)hipFree(h->clk_buf);
-  if (h->clk_stop) (void)hipHostFree((void*)h->clk_stop);
-  if (h->clk_stream) (void)hipStreamDestroy(h->clk_stream);
+  if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);
@@ -152,6 +148,12 @@ extern "C" const char* mgp_last_error(mgp_handle* h) { return h ? h->err : "inva
 
 extern "C" int mgp_profile_enable(mgp_handle* h, int on) {
   if (!h) return MGP_E_BADARG;
+  if (on) {  // clock stamps of the profiled launches: a fixed block (bench-only: allocated outside the workspace)
+    const size_t bytes = (size_t)MGP_PROF_CLK_LAUNCHES * MGP_PROF_CLK_WORDS * sizeof(unsigned long long);
+    if (!h->prof_clk) MGP_HIP(h, hipMalloc(&h->prof_clk, bytes));
+    MGP_HIP(h, hipMemsetAsync(h->prof_clk, 0, bytes, h->stream));
+    h->prof_clk_launches = 0;
+  }
   h->prof_on = on != 0;
   h->prof_used = 0;
   return MGP_OK;
@@ -186,74 +188,30 @@ extern "C" int mgp_profile_read_each(mgp_handle* h, double* ms_out, int64_t capa
   return MGP_OK;
 }
 
-// ---- sustained shader clock during a measured region (bench.py's roofline: the issue-slot fraction at the clock
-// the chip actually held, not only at the 2.4 GHz of the datasheet).  ONE wave on a stream of its own takes
-// (s_memrealtime, s_memtime) pairs -- the 100 MHz constant counter and the shader-clock counter -- sleeping in
-// between, until the host raises a flag in pinned memory or `max_samples` are taken (the exit every run reaches).
-// It is started BEFORE the measured launches so that it is resident; it holds one wave slot and issues ~nothing.
-namespace {
-__global__ __launch_bounds__(64) void clock_sampler_kernel(unsigned long long* __restrict__ out, int max_samples,
-                                                           const volatile int* stop) {
-  if (threadIdx.x != 0) return;
-  int i = 0;
-  for (; i < max_samples; ++i) {
-    out[2 + 2 * i] = __builtin_amdgcn_s_memrealtime();
-    out[3 + 2 * i] = __builtin_amdgcn_s_memtime();
-    if (*stop) {
-      ++i;
-      break;
-    }
-    for (int j = 0; j < 8; ++j) __builtin_amdgcn_s_sleep(127);  // 8 x 127 x 64 cycles: ~30 us between samples
-  }
-  out[0] = (unsigned long long)i;
-}
-}  // namespace
-
-extern "C" int mgp_profile_clock_begin(mgp_handle* h, int32_t max_samples) {
-  if (!h) return MGP_E_BADARG;
-  if (max_samples < 2 || max_samples > (1 << 20)) return mgp_fail(h, MGP_E_BADARG, "max_samples outside [2, 2^20]");
-  if (h->clk_running) return mgp_fail(h, MGP_E_BADARG, "clock sampler already running");
-  if (!h->clk_stream) MGP_HIP(h, hipStreamCreateWithFlags(&h->clk_stream, hipStreamNonBlocking));
-  if (!h->clk_stop) MGP_HIP(h, hipHostMalloc((void**)&h->clk_stop, sizeof(int), hipHostMallocMapped));
-  const size_t need = (size_t)(2 + 2 * max_samples) * sizeof(unsigned long long);
-  if (need > h->clk_bytes) {
-    if (h->clk_buf) MGP_HIP(h, hipFree(h->clk_buf));
-    h->clk_buf = nullptr;
-    h->clk_bytes = 0;
-    MGP_HIP(h, hipMalloc(&h->clk_buf, need));
-    h->clk_bytes = need;
-  }
-  *h->clk_stop = 0;
-  int* dstop = nullptr;
-  MGP_HIP(h, hipHostGetDevicePointer((void**)&dstop, (void*)h->clk_stop, 0));
-  MGP_HIP(h, hipMemsetAsync(h->clk_buf, 0, 2 * sizeof(unsigned long long), h->clk_stream));
-  hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, h->clk_stream, (unsigned long long*)h->clk_buf,
-                     max_samples, (const volatile int*)dstop);
-  MGP_LAUNCH_CHECK(h);
-  h->clk_running = true;
-  h->clk_cap = max_samples;
-  return MGP_OK;
-}
-
-// stops the sampler and returns the shader clock of every interval between consecutive samples, in MHz
-extern "C" int mgp_profile_clock_end(mgp_handle* h, double* mhz_out, int64_t capacity, int64_t* intervals) {
-  if (!h || !intervals || (capacity > 0 && !mhz_out)) return MGP_E_BADARG;
-  if (!h->clk_running) return mgp_fail(h, MGP_E_BADARG, "clock sampler not running");
-  *h->clk_stop = 1;
-  MGP_HIP(h, hipStreamSynchronize(h->clk_stream));
-  h->clk_running = false;
-  std::vector<unsigned long long> buf((size_t)2 + 2 * (size_t)h->clk_cap);
-  MGP_HIP(h, hipMemcpy(buf.data(), h->clk_buf, buf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  const int64_t n = (int64_t)buf[0];
+// ---- sustained shader clock of the profiled sweep launches (bench.py's roofline: the issue-slot fraction at the
+// clock the chip actually held, not only at the 2.4 GHz of the datasheet).  While profiling is on, up to 16
+// workgroups of every bracketed sweep launch stamp (s_memrealtime, s_memtime) -- the 100 MHz constant counter and
+// the shader-clock counter -- when they start and when their loop has ended (mgp_prof_stamp, mgp_common.h); the
+// clock a workgroup saw is the ratio of the two differences.  A resident sampling wave on a second stream was the
+// first form and was measured to PERTURB the kernel it watched (one CU can then hold one 512-thread workgroup
+// instead of two: a rank's 0.326 ms sweep took 0.383 ms), so the stamps ride inside the launch instead.
+extern "C" int mgp_profile_read_clocks(mgp_handle* h, double* mhz_out, int64_t capacity, int64_t* samples) {
+  if (!h || !samples || (capacity > 0 && !mhz_out)) return MGP_E_BADARG;
+  *samples = 0;
+  if (!h->prof_clk || h->prof_clk_launches == 0) return MGP_OK;
+  MGP_HIP(h, hipStreamSynchronize(h->stream));
+  const size_t nl = h->prof_clk_launches < (size_t)MGP_PROF_CLK_LAUNCHES ? h->prof_clk_launches : (size_t)MGP_PROF_CLK_LAUNCHES;
+  std::vector<unsigned long long> buf(nl * MGP_PROF_CLK_WORDS);
+  MGP_HIP(h, hipMemcpy(buf.data(), h->prof_clk, buf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   int64_t k = 0;
-  for (int64_t i = 1; i < n; ++i) {
-    const double dreal = (double)(buf[2 + 2 * i] - buf[2 + 2 * (i - 1)]);  // 100 MHz ticks
-    const double dclk = (double)(buf[3 + 2 * i] - buf[3 + 2 * (i - 1)]);
-    if (dreal <= 0) continue;
-    if (k < capacity) mhz_out[k] = dclk / dreal * 100.0;
-    ++k;
-  }
-  *intervals = k;
+  for (size_t l = 0; l < nl; ++l)
+    for (int sl = 0; sl < 16; ++sl) {
+      const unsigned long long* w = &buf[l * MGP_PROF_CLK_WORDS + 4 * sl];
+      if (w[0] == 0 || w[2] <= w[0] || w[3] <= w[1]) continue;  // slot not used / workgroup left early
+      if (k < capacity) mhz_out[k] = (double)(w[3] - w[1]) / (double)(w[2] - w[0]) * 100.0;
+      ++k;
+    }
+  *samples = k;
   return MGP_OK;
 }
 

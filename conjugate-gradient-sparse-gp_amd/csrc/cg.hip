@@ -168,8 +168,16 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
                                                              const T* __restrict__ ap, T* __restrict__ rz,
                                                              int* __restrict__ over, T* __restrict__ err, long n,
                                                              T thr, T min_float, const T* __restrict__ dinv,
-                                                             int max_it, int ap_slices, long ap_stride) {
+                                                             int max_it, int ap_slices, long ap_stride,
+                                                             const T* __restrict__ agree, int world) {
   if (ctrl->active == 0) return;
+  // multi-rank SGPR operator: `ap` is the all-reduced partial itself and `agree` the word behind it -- the sum of
+  // the ranks' gate words.  Unless every rank computed this application nobody uses it: the gate closes and all
+  // ranks leave the loop on the same iteration (what finish_allreduce_kernel did in a launch of its own).
+  if (agree != nullptr && *agree != (T)world) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->active = 0;
+    return;
+  }
   __shared__ T red[2][NT / 64];
   __shared__ int last_flag;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -407,8 +415,12 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       }
       long rb = op->kmm_row_begin, re = op->kmm_row_end;
       if (rb == 0 && re == 0) re = M;  // unset: this rank owns every row of Kmm
+      bool word_written = false;
       if (Bt == 1) {
-        MGP_TRY(mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, op->s2, tt, gate));
+        // with a collective the slab product also writes this rank's agreement word behind the partial
+        word_written = coll && re > rb && h->fuse_agree;
+        MGP_TRY(mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, op->s2, tt, gate,
+                                       word_written ? (void*)(tt + Bt * M) : nullptr));
       } else {
         // several RHS: full replicated product, then only this rank's slab of it is added
         T* kmp = u + Bt * N + Bt * M + 2;
@@ -419,8 +431,10 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       }
       if (coll) {
         const long tot = Bt * M;
-        hipLaunchKernelGGL((put_gate_word_kernel<T>), dim3(1), dim3(1), 0, h->stream, gate, tt + tot);
-        MGP_LAUNCH_CHECK(h);
+        if (!word_written) {
+          hipLaunchKernelGGL((put_gate_word_kernel<T>), dim3(1), dim3(1), 0, h->stream, gate, tt + tot);
+          MGP_LAUNCH_CHECK(h);
+        }
         if (op->allreduce) {  // rehearsal hook (gloo with host staging); never used with RCCL
           const int rc = op->allreduce(op->allreduce_ctx, tt, (size_t)(tot + 1), op->dtype, (void*)h->stream);
           if (rc != 0) return mgp_fail(h, MGP_E_COMM, "allreduce callback returned %d", rc);
@@ -428,6 +442,11 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
           MGP_TRY(mgp_comm_allreduce_on(h, op->comm, tt, (size_t)(tot + 1), op->dtype));
         }
         const int world = op->comm ? mgp_comm_size(op->comm) : op->world_size;
+        if (h->defer_finish && gate != nullptr) {  // the fused update tests the word and reads the partial in place
+          h->deferred_tt = tt;
+          h->deferred_world = world;
+          return MGP_OK;
+        }
         hipLaunchKernelGGL((finish_allreduce_kernel<T>), dim3(nblk(tot)), dim3(256), 0, h->stream, (int*)gate,
                            (const T*)tt, out, tot, world);
         MGP_LAUNCH_CHECK(h);
@@ -590,8 +609,11 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
       const bool defer = !reset && fused_ept > 0 && op->kind == MGP_OP_DENSE && h->skinny_defer;
       h->defer_slices = defer;
       h->deferred_ks = 1;
+      h->defer_finish = !reset && fused_ept > 0 && op->kind == MGP_OP_SGPR && h->fuse_agree;
+      h->deferred_tt = nullptr;
       const int rc_apply = apply_operator<T>(h, op, p, Bt, ap, &ctrl->active);
       h->defer_slices = false;
+      h->defer_finish = false;
       MGP_TRY(rc_apply);
       if (!reset && fused_ept > 0) {
         const T* dinv = pc.kind == MGP_PRE_JACOBI ? (const T*)pc.diag_inv : nullptr;
@@ -603,9 +625,17 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
           ap_slices = h->deferred_ks;
           ap_stride = h->deferred_stride;
         }
+        const T* agree = nullptr;
+        int world = 0;
+        if (h->deferred_tt != nullptr) {  // all-reduced partial left in place by the operator: [Bt, n] + word
+          ap_src = (const T*)h->deferred_tt;
+          agree = ap_src + tot;
+          world = h->deferred_world;
+        }
 #define MGP_FUSED(EPTV, NTV)                                                                                   \
   hipLaunchKernelGGL((cg_update_fused_kernel<T, EPTV, NTV>), dim3((unsigned)Bt), dim3(NTV), 0, s, ctrl, V, r, p,    \
-                     ap_src, rz, over, err_out, n, (T)thr, (T)min_float, dinv, (int)max_it, ap_slices, ap_stride)
+                     ap_src, rz, over, err_out, n, (T)thr, (T)min_float, dinv, (int)max_it, ap_slices, ap_stride, agree, \
+                     world)
         switch (fused_ept) {
           case 1: MGP_FUSED(1, 256); break;
           case 2: MGP_FUSED(2, 256); break;

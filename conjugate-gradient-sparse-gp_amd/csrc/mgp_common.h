@@ -94,6 +94,13 @@ struct mgp_handle {
   const void* deferred_part = nullptr;
   int deferred_ks = 1;
   long deferred_stride = 0;
+  // Deferred agreement check of the multi-rank SGPR operator (cg.hip): while `defer_finish` is set the operator
+  // leaves the all-reduced partial where the collective put it and reports it here; the fused CG update reads A.p
+  // from there and does finish_allreduce_kernel's test itself (agreement word == ranks, else the gate closes)
+  int fuse_agree = 1;  // MGP_FUSE_AGREE=0: put_gate_word_kernel + finish_allreduce_kernel as launches of their own
+  bool defer_finish = false;
+  const void* deferred_tt = nullptr;
+  int deferred_world = 0;
   int skinny_defer = 1;  // MGP_SKINNY_DEFER=0 keeps the separate reduce launch inside the CG loop
   int skinny_pipe = 1;  // software-pipelined form of the LDS-staged product when n % 64 == 0 and Bt <= 64 (MGP_SKINNY_PIPE=0: the round-1 form)
   int skinny_mode = 1;  // 2 <= Bt <= 128 product: 1 = P staged through LDS, 0 = register operands (MGP_SKINNY=reg)
@@ -102,13 +109,9 @@ struct mgp_handle {
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
-  // bench-only: shader-clock sampler (mgp_profile_clock_begin / _end), one wave on its own stream
-  hipStream_t clk_stream = nullptr;
-  void* clk_buf = nullptr;
-  size_t clk_bytes = 0;
-  volatile int* clk_stop = nullptr;  // pinned, mapped
-  bool clk_running = false;
-  int clk_cap = 0;
+  // bench-only: clock stamps of the profiled sweep launches (mgp_profile_read_clocks): 16 slots of 4 words each
+  void* prof_clk = nullptr;
+  size_t prof_clk_launches = 0;
 };
 
 // scope guard of mgp_pcg_solve: packs made during the solve are reused by its later iterations
@@ -123,6 +126,28 @@ struct PackHold {
     h->pack[0].valid = h->pack[1].valid = false;
   }
 };
+
+constexpr int MGP_PROF_CLK_WORDS = 64;        // per profiled launch: 16 slots x (real0, clk0, real1, clk1)
+constexpr int MGP_PROF_CLK_LAUNCHES = 8192;  // launches with stamps between two mgp_profile_enable(1) calls
+
+// the stamp slot block of the NEXT profiled launch (nullptr when profiling is off or the block is used up)
+inline unsigned long long* mgp_prof_clk_next(mgp_handle* h) {
+  if (!h->prof_on || !h->prof_clk || h->prof_clk_launches >= (size_t)MGP_PROF_CLK_LAUNCHES) return nullptr;
+  return (unsigned long long*)h->prof_clk + (h->prof_clk_launches++) * MGP_PROF_CLK_WORDS;
+}
+
+// which = 0 at the start of a workgroup, 1 when its loop has ended: 16 evenly spaced workgroups of the launch stamp
+// (constant 100 MHz counter, shader-clock counter).  One lane, two scalar reads, one 16-byte store; nothing is kept
+// in registers in between.
+__device__ __forceinline__ void mgp_prof_stamp(unsigned long long* clk, int which) {
+  if (clk == nullptr) return;
+  const unsigned stride = gridDim.x >= 16 ? gridDim.x >> 4 : 1;
+  const unsigned slot = blockIdx.x / stride;
+  if (blockIdx.x == slot * stride && slot < 16 && threadIdx.x == 0) {
+    clk[4 * slot + 2 * which] = __builtin_amdgcn_s_memrealtime();
+    clk[4 * slot + 2 * which + 1] = __builtin_amdgcn_s_memtime();
+  }
+}
 
 // returns the stop event to record after the launch (nullptr when profiling is off)
 inline hipEvent_t mgp_prof_begin(mgp_handle* h) {
@@ -308,7 +333,7 @@ int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64
                       int accumulate, int nz, const int* tile_tab, int ntiles);
 int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale);
 int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
-                           double alpha, void* out, const int* gate);
+                           double alpha, void* out, const int* gate, void* word = nullptr);
 // comm.hip: the operator's all-reduce on the handle's stream (errors land in the handle)
 int mgp_comm_allreduce_on(mgp_handle* h, mgp_comm* comm, void* buf, size_t count, int dtype);
 int mgp_symm_matmul_gated(mgp_handle* h, int dtype, const void* A, int64_t n, const void* P, int64_t Bt,

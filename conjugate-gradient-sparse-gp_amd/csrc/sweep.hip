@@ -35,8 +35,9 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
     const T* __restrict__ A, long na, const T* __restrict__ B, long nb, long b_chunk,
     const T* __restrict__ W, long w_sj, long w_sr, T* __restrict__ out, long o_si, long o_sr,
     long o_chunk, int D, SweepParams prm, T alpha, const T* __restrict__ addend, long ad_si,
-    long ad_sr, const int* __restrict__ gate, int nblk, int nchunks) {
+    long ad_sr, const int* __restrict__ gate, int nblk, int nchunks, unsigned long long* __restrict__ clk) {
   if (gate != nullptr && *gate == 0) return;
+  mgp_prof_stamp(clk, 0);
   // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so the
   // nblk workgroups that stream the SAME chunk of broadcast points get linear ids that differ by
   // multiples of 8 (same XCD, dispatched together) and share the chunk through that XCD's L2.
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(kThreads, (DP <= 8 && RC == 1) ? 4 : 1) void sweep_
     }
   }
 
+  mgp_prof_stamp(clk, 1);
   const T var = SQ ? (T)(prm.variance * prm.variance) : (T)prm.variance;
   bool folded = false;
   if (FOLD32 && jb < je) {  // the loop ran, so amax_w is published (its barrier precedes the first tile)
@@ -417,8 +419,9 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT 
     const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_sr, long o_chunk, int D,
     SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, long ad_sr,
     const int* __restrict__ gate, int nblk, int nchunks, const unsigned long long* __restrict__ bmax_bits,
-    int pf_mask, int pf_ahead, const double* __restrict__ gtab) {
+    int pf_mask, int pf_ahead, const double* __restrict__ gtab, unsigned long long* __restrict__ clk) {
   if (gate != nullptr && *gate == 0) return;
+  mgp_prof_stamp(clk, 0);
   const int lin = blockIdx.x;
   int bx, by;
   if ((nchunks & 7) == 0) {  // XCD-aware decode, as sweep_kernel: the workgroups that stream one chunk share an XCD
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT 
     else
       sweep_loop(std::true_type{});
   }
+  mgp_prof_stamp(clk, 1);
 
   double* o = out + (long)by * o_chunk;
 #pragma unroll
@@ -913,12 +917,13 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
         a_add = nullptr;
         a_si = a_sr = 0;
       }
+      unsigned long long* clk = mgp_prof_clk_next(h);
       hipEvent_t stop = mgp_prof_begin(h);
 #define MGP_FAST_LAUNCH(RPTV, NTV, TB, DB)                                                                       \
   hipLaunchKernelGGL((sweep_fast_kernel<DP, KIND, RC, RPTV, NTV, TB, DB>), grid, dim3(NTV), 0, h->stream, A, na, Pk, \
                      nb, b_chunk, W, w_sj, dst, d_si, d_sr, d_chunk, D, prm, a_alpha, a_add, a_si, a_sr, gate,        \
                      (int)nblk, (int)nchunks, bmax, h->pf_trips - 1, h->pf_ahead,                                    \
-                     (const double*)h->e2tabs + (TB == 13 ? 0 : 8192))
+                     (const double*)h->e2tabs + (TB == 13 ? 0 : 8192), clk)
       if constexpr (RC > 1) {
         // two SGPR copies of (row, weights) while they fit: (DP + 1 + RC) doubles each
         if constexpr (DP > 16) {
@@ -955,10 +960,11 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
     }
   }
   if (nchunks == 1) {
+    unsigned long long* clk = mgp_prof_clk_next(h);
     hipEvent_t stop = mgp_prof_begin(h);
     hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC, SQ>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                        b_chunk, W, w_sj, w_sr, out, o_si, o_sr, 0L, D, prm, alpha, addend, ad_si, ad_sr, gate, (int)nblk,
-                       (int)nchunks);
+                       (int)nchunks, clk);
     mgp_prof_end(h, stop);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;
@@ -966,10 +972,11 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   const size_t need = (size_t)nchunks * na * RC * sizeof(T);
   MGP_TRY(mgp_reserve(h, &h->ws, &h->ws_bytes, need));
   T* part = (T*)h->ws;
+  unsigned long long* clk = mgp_prof_clk_next(h);
   hipEvent_t stop = mgp_prof_begin(h);
   hipLaunchKernelGGL((sweep_kernel<T, DP, KIND, RC, SQ>), grid, dim3(kThreads), 0, h->stream, A, na, B, nb,
                      b_chunk, W, w_sj, w_sr, part, 1L, na, na * (long)RC, D, prm, (T)0, (const T*)nullptr, 0L,
-                     0L, gate, (int)nblk, (int)nchunks);
+                     0L, gate, (int)nblk, (int)nchunks, clk);
   mgp_prof_end(h, stop);
   MGP_LAUNCH_CHECK(h);
   launch_reduce_partials<T>(h, part, na, RC, (int)nchunks, out, o_si, o_sr, alpha, addend, ad_si, ad_sr, gate);

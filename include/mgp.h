@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 210 /* 0.2.1: + mgp_profile_clock_begin/_end (0.2.0: mgp_comm, mgp_operator.comm, mgp_create_ex) */
+#define MGP_VERSION 210 /* 0.2.1: + mgp_profile_read_clocks (0.2.0: mgp_comm, mgp_operator.comm, mgp_create_ex) */
 #define MGP_MAX_D 512      /* input dimensions the library accepts (capacity of mgp_kernel) */
 #define MGP_FUSED_MAX_D 32 /* up to here the fused register-resident sweeps run; above, products go through
                             * row-chunked explicit kernel panels + the NT GEMM (the reference's dense form);
@@ -268,12 +268,10 @@ int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms);
 /* as mgp_profile_read, but one duration per bracketed launch (the first `capacity` of them) so the
  * caller can report median / percentiles; *launches receives the number recorded. */
 int mgp_profile_read_each(mgp_handle* h, double* ms_out, int64_t capacity, int64_t* launches);
-/* Sustained shader clock over a measured region (bench-only).  _begin starts ONE wave on a stream of the library's
- * own that records (constant 100 MHz counter, shader-clock counter) pairs about every 30 us until _end is called or
- * max_samples are taken; _end stops it and returns the clock of every interval between consecutive samples in MHz
- * (the first `capacity` of them) and their number.  Start it before the launches to be measured. */
-int mgp_profile_clock_begin(mgp_handle* h, int32_t max_samples);
-int mgp_profile_clock_end(mgp_handle* h, double* mhz_out, int64_t capacity, int64_t* intervals);
+/* Shader clock the bracketed sweep launches ran at (bench-only): while profiling is on, up to 16 workgroups of each
+ * launch stamp the constant 100 MHz counter and the shader-clock counter at their start and at the end of their loop;
+ * this returns one value in MHz per stamped workgroup (the first `capacity` of them) and their number. */
+int mgp_profile_read_clocks(mgp_handle* h, double* mhz_out, int64_t capacity, int64_t* samples);
 
 /* ---- next row F3: cover-tree clustering (host code, no GPU, no handle) ----------------------
  * Replaces the reference's CoverTree class (cggp/covertree.py:26-179), which
