@@ -16,6 +16,10 @@ sys.path.insert(0, os.path.join(ROOT, "conjugate-gradient-sparse-gp_amd"))
 from cggp import synthetic  # noqa: E402
 
 tag = sys.argv[1]
+# the instantiation launch_sweep picks for each config (csrc/sweep.hip; rocprofv3 truncates the templated names)
+KERNEL_NAMES = {"C3": "sweep_fast_kernel<DP=8, SE, RC=1, RPT=4, NT=512, TBITS=13, DBUF=true>",
+                "C4": "sweep_kernel<float, DP=2, SE, RC=1>  (LDS tile, v_exp_f32, v_pk_fma_f32)",
+                "C5": "sweep_fast_kernel<DP=32, Matern32, RC=1, RPT=2, NT=256, TBITS=11, DBUF=false>"}
 out = {"what": "PMC model of the fused sweep per BASELINE config: VALU-busy quad-cycles per wave-pair (64 pair "
                "evaluations), from rocprofv3 --pmc passes (tools/pmc_sweep.sh; one counter set per pass) over "
                "tools/run_sweep.py.  bench.py: frac = pairs_per_launch / 64 * active_valu_quadcycles_per_wave_pair * 4 "
@@ -41,7 +45,7 @@ for arg in sys.argv[2:]:
                           f"tools/run_sweep.py: 3 x K_nm.v + 3 x K_mn.u, {cfg}: N={N} D={D} M={M} {dt} {kname}, R=1; "
                           "means per dispatch)", "launches": summ}, open(os.path.join(ROOT, raw), "w"), indent=1)
     out["configs"][cfg] = {
-        "kernel": sorted(launches)[0].split(" grid=")[0].replace(" [kmn]", "").replace(" [knm]", ""),
+        "kernel": KERNEL_NAMES.get(cfg, ""),
         "N": N, "D": D, "M": M, "dtype": dt, "kernel_kind": kname, "pairs_per_launch": pairs,
         "active_valu_quadcycles_per_wave_pair": sum(q) / len(q),
         "active_valu_quadcycles_per_wave_pair_by_launch": dict(zip(sorted(launches), [q[i] for i in sorted(range(len(q)), key=lambda i: sorted(launches).index(list(launches)[i]))])),
