@@ -107,15 +107,17 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const T* __restrict__ b, c
 //   4  second half with z already in memory (dense preconditioner), normal beta
 //   5  second half with z already in memory, beta = 0 (start-up and refresh: p = z)
 // `force` bypasses the gate (start-up of the dense-preconditioner path).
+// Block size: 256 threads per right-hand side up to n = 8192, 1024 beyond (the fused kernel covers n <= 8192; one
+// 256-thread workgroup per right-hand side was a cliff for larger systems).
 template <typename T>
-__global__ __launch_bounds__(256) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
+__global__ __launch_bounds__(1024) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
                                                         T* __restrict__ r, T* __restrict__ p,
                                                         T* __restrict__ z, const T* __restrict__ ap,
                                                         T* __restrict__ rz, int* __restrict__ over,
                                                         T* __restrict__ err, long n, T thr, T min_float,
                                                         PrecondDev pc, int mode, int force) {
   if (!force && ctrl->active == 0) return;
-  __shared__ T red[8];
+  __shared__ T red[16];
   const long off = (long)blockIdx.x * n;
   const T rz_old = rz[blockIdx.x];
   const bool first = mode == 0 || mode == 1 || mode == 3;
@@ -535,6 +537,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   CgCtrl* ctrl = (CgCtrl*)(((uintptr_t)(over + Bt) + 15) & ~(uintptr_t)15);
   void* d1_arena = (void*)(((uintptr_t)(ctrl + 1) + 15) & ~(uintptr_t)15);
   hipStream_t s = h->stream;
+  const unsigned upd_threads = n > 8192 ? 1024u : 256u;  // generic update kernel: threads per right-hand side
   // z = M^-1 r for the preconditioners applied outside the update kernels
   auto external_z = [&](const int* gate) -> int {
     if (cb) {
@@ -568,7 +571,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, av, r, tot, 1);
     MGP_LAUNCH_CHECK(h);
     MGP_TRY(external_z(nullptr));
-    hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz, over,
+    hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz, over,
                        err_out, n, (T)thr, (T)min_float, pc, 5, 1);
     MGP_LAUNCH_CHECK(h);
   }
@@ -650,25 +653,25 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
         continue;  // bookkeeping done inside the kernel
       } else if (!reset) {
         if (!dense_pre) {
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 0, 0);
         } else {
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 3, 0);
           MGP_LAUNCH_CHECK(h);
           MGP_TRY(external_z(&ctrl->active));
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 4, 0);
         }
       } else {
-        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, 1, 0);
         MGP_LAUNCH_CHECK(h);
         MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, &ctrl->active));
         hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot, 0);
         MGP_LAUNCH_CHECK(h);
         if (dense_pre) MGP_TRY(external_z(&ctrl->active));
-        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, ctrl, V, r, p, z, ap, rz,
+        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, dense_pre ? 5 : 2, 0);
       }
       MGP_LAUNCH_CHECK(h);

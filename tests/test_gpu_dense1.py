@@ -228,3 +228,21 @@ def test_cdgp_predict_mean_through_the_dense_path():
                   num_probes=None, pseudo_u=u, cluster_counts=counts)
     mu0, var0 = ref.predict_f(syn.X[:64])
     assert relerr(mu, mu0) < 1e-6 and float(np.max(np.abs(var.cpu().numpy() - var0))) < 1e-6
+
+
+@pytest.mark.parametrize("Bt", [1, 3])
+def test_beyond_the_fused_sizes(Bt):
+    """n > 8192: neither the two-launch path nor the register-resident fused update applies; the generic update
+    kernel (1024 threads per right-hand side there) runs the same recurrence, with and without Jacobi."""
+    from cggp.conjugate_gradient import JacobiPreconditioner, conjugate_gradient
+    n = 9001
+    rng = np.random.default_rng(31)
+    Q = rng.standard_normal((n, 40))
+    A = Q @ Q.T / 40 + np.diag(1.0 + rng.random(n))
+    rhs = rng.standard_normal((Bt, n))
+    for pre, o_pre in ((None, None), (JacobiPreconditioner(), ocg.JacobiPreconditioner())):
+        sol, (steps, err) = conjugate_gradient(T(A), T(rhs), None, 0.0, pre, max_iterations=6, max_steps_cycle=7)
+        o_sol, (o_steps, o_err) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), 0.0, o_pre, max_iterations=6,
+                                                         max_steps_cycle=7)
+        assert int(steps) == 6 == o_steps and relerr(sol, o_sol) < 1e-9
+        assert np.max(np.abs(err.cpu().numpy() - o_err) / np.abs(o_err)) < 1e-6
