@@ -212,3 +212,55 @@ def test_c5_sgpr_cg_steps_against_oracle():
     true_half = 0.5 * float((r * r).sum())
     assert int(kf) == steps and abs(true_half - float(errf)) / true_half < 1e-8
     assert true_half < 0.5 * float((rhsf * rhsf).sum())
+
+
+def test_c2_cdgp_end_to_end_elbo_and_full_covariance():
+    """BASELINE.json configs[1] ("CDGP RBF N=100k, D=8, M=2048 ... CG") as one pipeline at its stated size:
+    nearest-centre assignment and cluster statistics over all 100 000 rows against `oracle/cluster.py`, then at
+    M = 2048 the exact-trace KL (`models.py:304-306`: an M-column CG), the ELBO of a 4096-row minibatch with the
+    reference's scale N / batch (`models.py:125-134,163-169`), the full predictive covariance of a 128-row batch
+    (`models.py:347-349`), and mean + variance of EVERY row through `predict_f_batched` -- against closed forms from
+    the oracle's Cholesky twin (CGGP's KL omits 0.5 log|Kmm+Lambda|, `models.py:46,319`: twin KL minus that term)."""
+    from cggp import kernels, synthetic
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.models import CGGP
+    from cggp.optimize import assign_inducing_parameters, oips_update_inducing_parameters
+    from oracle import cluster as oc
+    N, D, M, dt, kname = synthetic.CONFIGS["C2"]
+    syn = synthetic.make_inputs(N, D, M, dt)
+    X, y, Z = (torch.from_numpy(a).to(dev()) for a in (syn.X, syn.y, syn.Z))
+    kern = kernels.SquaredExponential(1.0, [1.0] * D)
+    m = CGGP(kern, 0.1, Z, ConjugateGradient(1e-13, max_iterations=4 * M), num_probes=None, num_data=N)
+    assign_inducing_parameters(m, *oips_update_inducing_parameters(m, (X, y), Z))
+    idx = oc.nearest_centre_sqdist(syn.Z, syn.X)
+    u, counts = oc.cluster_stats(idx, syn.y, M)
+    assert np.array_equal(m.cluster_counts.cpu().numpy(), counts)
+    assert np.max(np.abs(m.pseudo_u.cpu().numpy() - u)) < 1e-12
+    ko = ok.Kernel(kname, 1.0, np.ones(D))
+    twin = om.ClusterGP(ko, 0.1, syn.Z, pseudo_u=u, cluster_counts=counts, num_data=N)
+    Kmm, KL = twin._KmmLambda()
+    logdet = np.linalg.slogdet(KL)[1]
+    kl_exact = twin.prior_kl() - 0.5 * logdet
+    kl = m.prior_kl()
+    assert abs(kl - kl_exact) / abs(kl_exact) < 1e-8, (kl, kl_exact)
+    # minibatch ELBO, scale = N / 4096
+    nb = 4096
+    xb, yb = syn.X[:nb], syn.y[:nb]
+    mu_c, var_c = twin.predict_f(xb)
+    ve = om.gaussian_variational_expectations(mu_c, var_c, yb, twin.noise_variance)
+    elbo_exact = np.sum(ve) * (N / nb) - kl_exact
+    elbo = m.elbo((X[:nb], y[:nb]))
+    assert abs(elbo - elbo_exact) / abs(elbo_exact) < 1e-7, (elbo, elbo_exact)
+    # full covariance of a batch
+    _, cov = m.predict_f(X[:128], full_cov=True)
+    _, cov_c = twin.predict_f(syn.X[:128], full_cov=True)
+    assert cov.shape == (1, 128, 128)
+    assert float(np.max(np.abs(cov.cpu().numpy() - cov_c))) < 1e-7
+    # every row, both forms of the batched prediction against each other and spot rows against the twin
+    m.conjugate_gradient = ConjugateGradient(1e-6)
+    mu_s, var_s = m.predict_f_batched(X, 8192, shared_inverse=True)
+    assert mu_s.shape == (N, 1) and var_s.shape == (N, 1) and float(var_s.min()) > 0
+    rows = np.r_[0, N - 1, np.random.default_rng(3).integers(0, N, 510)]
+    mu_r, var_r = twin.predict_f(syn.X[rows])
+    assert _rel(mu_s.cpu().numpy()[rows], mu_r) < 1e-3  # `a` is solved to the reference's 1e-6 threshold
+    assert float(np.max(np.abs(var_s.cpu().numpy()[rows] - var_r))) < 1e-6
