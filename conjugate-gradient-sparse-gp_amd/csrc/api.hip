@@ -28,6 +28,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (pa && atoi(pa) >= 0) h->pf_ahead = atoi(pa);
   const char* stg = getenv("MGP_SWEEP_TARGET");
   if (stg && atoi(stg) >= 1 && atoi(stg) <= 64) h->sweep_target_per_cu = atoi(stg);
+  const char* sgr = getenv("MGP_SWEEP_GRAN");
+  if (sgr && (atoi(sgr) == 64 || atoi(sgr) == 128 || atoi(sgr) == 256)) h->sweep_chunk_gran = atoi(sgr);
   const char* f32r = getenv("MGP_SWEEP_RPT32");
   if (f32r && (atoi(f32r) == 1 || atoi(f32r) == 2)) h->sweep_fast_rpt32 = atoi(f32r);
   const char* frc = getenv("MGP_SWEEP_RPT_RC");

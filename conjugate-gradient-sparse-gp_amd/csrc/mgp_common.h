@@ -64,6 +64,7 @@ struct mgp_handle {
   // and the younger fills its stalls, so each CU ends with one workgroup running alone at ~0.82 of the rate of two --
   // the shorter the workgroups, the shorter that tail (C3: 4.75 -> 4.66 ms per CG step against 8)
   int sweep_target_per_cu = 16;
+  int sweep_chunk_gran = 256;  // streamed points per chunk are a multiple of this in the fast kernel (MGP_SWEEP_GRAN: 64, 128, 256)
   int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
   int sweep_fast_rpt_rc = 2;  // owned points per lane with 2 or 4 right-hand sides at D <= 8 (2 or 3) -- MGP_SWEEP_RPT_RC
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT

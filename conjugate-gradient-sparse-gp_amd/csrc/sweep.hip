@@ -855,11 +855,14 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   // (measured 2.41 -> 2.26 ms with two chunks); the LDS-tile kernels keep the round-1 threshold
   const long nosplit = frpt ? (h->nosplit_per_cu > 8 ? h->nosplit_per_cu : 8) : h->nosplit_per_cu;
   long nchunks = nblk * (fnt / kThreads) >= nosplit * h->num_cus ? 1 : (target + nblk - 1) / nblk;
-  const long max_chunks = (nb + TB - 1) / TB;
+  // chunk granularity: the LDS-tile kernels stream whole tiles of TB points; the fast kernel has no tile and takes
+  // any even count (MGP_SWEEP_GRAN, default TB)
+  const long gran = frpt ? (long)h->sweep_chunk_gran : (long)TB;
+  const long max_chunks = (nb + gran - 1) / gran;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
   long b_chunk = (nb + nchunks - 1) / nchunks;
-  b_chunk = (b_chunk + TB - 1) / TB * TB;
+  b_chunk = (b_chunk + gran - 1) / gran * gran;
   nchunks = (nb + b_chunk - 1) / b_chunk;
   if (nchunks > 65535) return mgp_fail(h, MGP_E_SHAPE, "sweep: too many chunks");
   if (nblk * nchunks > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "sweep: grid too large");
