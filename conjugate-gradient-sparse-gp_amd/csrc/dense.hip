@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A,
   if (!open) return;
   constexpr int RW = 2;  // 4 rows per wave measured the same at n=4096 and 3% slower at n=8192
   const int lane = threadIdx.x & 63;
-  const long row0 = row_begin + ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RW;  // 1..4 waves per block
+  const long row0 = row_begin + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
   if (row0 >= row_end) return;
   T acc[RW][BT];
 #pragma unroll
@@ -169,6 +169,59 @@ __global__ __launch_bounds__(256) void symm_gemv_kernel(const T* __restrict__ A,
         *o = accumulate ? mgp_fma(alpha, s, *o) : s;
       }
     }
+}
+
+// A rank's slab of the replicated s2 Kmm.p term (few rows: 512 of 4096 at 8 ranks), accumulated into its partial:
+// out[row] += alpha * A[row, :] . p.  One workgroup per 2 rows with the COLUMNS split over its four waves, so that
+// 256 workgroups x 4 waves x 4 KB are in flight on the chip (one wave per 2 rows left 1 MB in flight: 12.5 us for
+// 16.8 MB whether the waves sat in 64 or in 256 workgroups); the four column sums of a row are added in wave order.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void symm_gemv_slab_kernel(const T* __restrict__ A, long n, const T* __restrict__ p,
+                                                             T* __restrict__ out, const int* __restrict__ gate,
+                                                             long row_begin, long row_end, T alpha,
+                                                             T* __restrict__ word) {
+  const bool open = gate == nullptr || *gate != 0;
+  if (word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *word = open ? (T)1 : (T)0;  // see symm_gemv_kernel
+  if (!open) return;
+  __shared__ T part[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row0 = row_begin + (long)blockIdx.x * 2;
+  const T* a0 = A + row0 * n;
+  const T* a1 = A + (row0 + 1 < row_end ? row0 + 1 : row0) * n;
+  // columns [c0, c1) of this wave: quarters rounded to whole vector groups of the wave
+  const long per = ((n + 3) / 4 + 64 * VEC - 1) / (64 * VEC) * (64 * VEC);
+  const long c0 = (long)wave * per, c1 = c0 + per < n ? c0 + per : n;
+  T s0 = 0, s1 = 0;
+#pragma unroll 4
+  for (long i = c0 + (long)lane * VEC; i < c1; i += 64 * VEC) {
+    if (VEC == 1) {
+      const T pv = p[i];
+      s0 = mgp_fma(a0[i], pv, s0);
+      s1 = mgp_fma(a1[i], pv, s1);
+    } else {
+      using V = __attribute__((ext_vector_type(VEC))) T;
+      const V x0 = *reinterpret_cast<const V*>(a0 + i), x1 = *reinterpret_cast<const V*>(a1 + i);
+      const V pv = *reinterpret_cast<const V*>(p + i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s0 = mgp_fma(x0[e], pv[e], s0);
+        s1 = mgp_fma(x1[e], pv[e], s1);
+      }
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) {
+    part[wave][0] = s0;
+    part[wave][1] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && row0 + threadIdx.x < row_end) {
+    const int q = threadIdx.x;
+    const T s = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+    T* o = &out[row0 + q];
+    *o = mgp_fma(alpha, s, *o);
+  }
 }
 
 // ------------------------------------------------------------------ one-RHS product on the upper triangle
@@ -1349,16 +1402,23 @@ int symm_gemv_rows_t(mgp_handle* h, const T* A, long n, const T* p, long rb, lon
   if (re <= rb) return MGP_OK;
   constexpr int VECW = 16 / sizeof(T);
   const bool vec = (n % VECW) == 0 && (((uintptr_t)A) % 16) == 0;
-  // a rank's slab is few rows (512 of 4096 at 8 ranks): one wave per workgroup then, so that 2 rows per wave still
-  // give every CU a workgroup (64 four-wave workgroups left three quarters of the chip idle: 12.1 us for 16.8 MB)
-  const int nthr = (re - rb) * 64 / 2 <= (long)h->num_cus * 256 ? 64 : 256;
-  const int rows_per_block = 2 * (nthr / 64);
-  dim3 grid((unsigned)((re - rb + rows_per_block - 1) / rows_per_block));
+  if ((re - rb) <= 2L * h->num_cus * 4 && n >= 1024) {  // a rank's slab: columns split over the waves of a workgroup
+    dim3 grid((unsigned)((re - rb + 1) / 2));
+    if (vec && (n % (64 * VECW)) == 0)
+      hipLaunchKernelGGL((symm_gemv_slab_kernel<T, VECW>), grid, dim3(256), 0, h->stream, A, n, p, out, gate, rb, re,
+                         alpha, word);
+    else
+      hipLaunchKernelGGL((symm_gemv_slab_kernel<T, 1>), grid, dim3(256), 0, h->stream, A, n, p, out, gate, rb, re,
+                         alpha, word);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
+  }
+  dim3 grid((unsigned)((re - rb + 7) / 8));
   if (vec)
-    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, VECW>), grid, dim3(nthr), 0, h->stream, A, n, p, 1, out, gate, rb, re,
+    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, VECW>), grid, dim3(256), 0, h->stream, A, n, p, 1, out, gate, rb, re,
                        alpha, 1, word);
   else
-    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, 1>), grid, dim3(nthr), 0, h->stream, A, n, p, 1, out, gate, rb, re,
+    hipLaunchKernelGGL((symm_gemv_kernel<T, 1, 1>), grid, dim3(256), 0, h->stream, A, n, p, 1, out, gate, rb, re,
                        alpha, 1, word);
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;

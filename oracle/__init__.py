@@ -27,6 +27,11 @@ Parity status (be precise about what is and is not pinned):
   twin `cggp/models.py:250-276`, SGPR-CG == two-Cholesky closed form) only:
   **parity unpinned** against GPflow outputs.
 
+* Independent third-party implementations installed here (scikit-learn's RBF / Matern kernels and
+  GaussianProcessRegressor, SciPy's conjugate gradient) agree with the restated formulas
+  (`tests/test_oracle_thirdparty.py`); that is a check of the restatement, not of GPflow's outputs,
+  and does not change the status above.
+
 Every function cites the reference file:line it follows.
 """
 

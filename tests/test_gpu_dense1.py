@@ -246,3 +246,38 @@ def test_beyond_the_fused_sizes(Bt):
                                                          max_steps_cycle=7)
         assert int(steps) == 6 == o_steps and relerr(sol, o_sol) < 1e-9
         assert np.max(np.abs(err.cpu().numpy() - o_err) / np.abs(o_err)) < 1e-6
+
+
+@pytest.mark.parametrize("M,G,dtype", [(2048, 8, torch.float64), (1500, 3, torch.float64), (1024, 4, torch.float32)])
+def test_rank_slabs_of_the_sgpr_operator_sum_to_the_whole(M, G, dtype):
+    """Multi-GPU decomposition of S.p at sizes where a rank's slab of s2 Kmm.p runs the column-split
+    slab kernel (M >= 1024): the partial operators of G ranks -- row shard of X, row slab of Kmm -- add up to the
+    whole operator, which the oracle checks."""
+    from cggp import kernels, parallel
+    from cggp.conjugate_gradient import SgprNormalOperator
+    N, D = 6000, 3
+    rng = np.random.default_rng(M + G)
+    X, Z = rng.standard_normal((N, D)), rng.standard_normal((M, D))
+    kern = kernels.Matern52(1.2, [0.9, 1.1, 1.3])
+    Xt, Zt = T(X, dtype), T(Z, dtype)
+    P = T(rng.standard_normal((1, M)), dtype)
+    whole = SgprNormalOperator(kern, Xt, Zt, 0.1, jitter=1e-6).rmatmul(P)
+    acc = torch.zeros_like(whole, dtype=torch.float64)
+
+    class _OneRank:  # the exchange of a one-rank group: the partial is its own sum (slabs are honoured only with one)
+        comm, world_size = None, 1
+
+        def __call__(self, t):
+            pass
+
+    for g in range(G):
+        lo, hi = parallel.shard_bounds(N, G, g)
+        part = SgprNormalOperator(kern, Xt[lo:hi].contiguous(), Zt, 0.1, jitter=1e-6, allreduce=_OneRank(),
+                                  kmm_rows=parallel.kmm_slab(M, G, g)).rmatmul(P)
+        acc += part.double()
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    assert float((acc - whole.double()).abs().max() / whole.double().abs().max()) < tol
+    if dtype == torch.float64:
+        ko = ok.Kernel("matern52", 1.2, np.array([0.9, 1.1, 1.3]))
+        ref = om.SgprNormalOperator(X, Z, ko, 0.1, jitter=1e-6).rmatmul(P.cpu().numpy())
+        assert relerr(whole, ref) < 1e-11

@@ -10,5 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${tag}_prof" -- python3 "$R/bench.py" > "$R/gpurun_out/${tag}_bench_under_rocprof.json" 2> "$R/gpurun_out/${tag}_rocprof.err"
 echo "rocprof rc=$?"
 cp "$R"/gpurun_out/${tag}_prof/*/*kernel_stats.csv "$R/gpurun_out/${tag}_kernel_stats.csv"
-python3 "$R/tools/show_stats.py" "$R/gpurun_out/${tag}_kernel_stats.csv" > "$R/gpurun_out/${tag}_kernel_stats_summary.txt"
+cp "$R"/gpurun_out/${tag}_prof/*/*kernel_trace.csv "$R/gpurun_out/${tag}_kernel_trace.csv"
+python3 "$R/tools/show_stats.py" "$R/gpurun_out/${tag}_kernel_stats.csv" "$R/gpurun_out/${tag}_kernel_trace.csv" > "$R/gpurun_out/${tag}_kernel_stats_summary.txt"
 head -5 "$R/gpurun_out/${tag}_kernel_stats_summary.txt"
