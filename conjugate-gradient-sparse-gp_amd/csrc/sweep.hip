@@ -413,8 +413,12 @@ __global__ __launch_bounds__(256) void build_e2tab_kernel(double* __restrict__ t
 // RC right-hand sides: the weights of a streamed point are RC consecutive doubles (w_sj = RC: the caller hands
 // the transposed copy made by transpose_weights_kernel), read by one scalar load into RC SGPR pairs; each
 // pair's kernel value feeds RC accumulators.
+#ifndef MGP_D32_WAVES
+#define MGP_D32_WAVES 3  // waves per SIMD the D = 32, two-points-per-lane instantiations are compiled for: 167 VGPRs (one under
+                         // the three-wave limit; the compiler took 171 when allowed 256) -- C5 sweep 7.86 -> 7.64 ms in an in-run A/B
+#endif
 template <int DP, int KIND, int RC, int RPT, int NT, int TBITS, bool DBUF>
-__global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : 2) : (RPT >= 4 || NT == 512 || DP > 8 ? 4 : (RPT == 3 ? 5 : 8))) void sweep_fast_kernel(
+__global__ __launch_bounds__(NT, DP > 16 ? (RPT == 1 ? 4 : MGP_D32_WAVES) : (RPT >= 4 || NT == 512 || DP > 8 ? 4 : (RPT == 3 ? 5 : 8))) void sweep_fast_kernel(
     const double* __restrict__ A, long na, const double* __restrict__ Pk, long nb, long b_chunk,
     const double* __restrict__ W, long w_sj, double* __restrict__ out, long o_si, long o_sr, long o_chunk, int D,
     SweepParams prm, double alpha, const double* __restrict__ addend, long ad_si, long ad_sr,

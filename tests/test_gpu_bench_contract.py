@@ -60,3 +60,24 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
     assert d["convergence_preconditioned"]["converged"] is True
     assert d["cdgp_same_size"]["cg_iterations"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rank_share_emulation():
+    """`--emulate-world W`: one rank's share of a W-GPU step on the one GPU of the box (N/W rows, the 1/W slab of
+    Kmm.p, the exchange on a one-rank libmgp communicator).  Timing only -- the other legs are skipped."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-world", "4", "--steps", "4",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert c["emulated_world"] == 4 and c["rows_per_gpu"] == (1 << 20) // 4 and c["kmm_rows_of_this_rank"] == [0, 1024]
+    assert "mgp_operator.comm" in c["collective"] and d["n_gpus"] == 1
+    assert d["cpu_baseline"] is None and d["convergence"] is None and d["cdgp_same_size"] is None
+    r = d["roofline"]
+    assert r["launches_timed"] == 8 and 0.3 < r["frac"] <= 1.0 and r["frac"] <= r["frac_at_sustained_clock"] <= 1.0
+    clk = r["sustained_clock"]
+    assert 1000 < clk["min_mhz"] <= clk["mean_mhz"] <= clk["max_mhz"] <= 2500 and clk["workgroups_sampled"] >= 8
+    assert r["traffic"] is None  # the PMC passes ran at the full size only
