@@ -42,7 +42,7 @@ def test_bench_constants_and_recomputation():
     assert abs(b.FP64_VECTOR_PEAK_TFLOPS - 1024 * 16 * 2 * 2.4e9 / 1e12) < 0.1
     assert b.EXECUTED_FLOPS_PER_PAIR[(8, "se")](8, 1) == 28 and b.SURVEY_FLOPS_PER_PAIR(8, 1) == 61
     # the committed line of this round recomputes from the model file
-    line_path = os.path.join(ROOT, "profiles", "r03_bench_c3.json")
+    line_path = os.path.join(ROOT, "profiles", "r03_final_bench.json")
     if os.path.exists(line_path):
         d = json.load(open(line_path))
         r = d["roofline"]
