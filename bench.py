@@ -205,7 +205,12 @@ def main():
     # rocprofv3 --pmc passes of tools/pmc_sweep.sh)
     model, model_src = None, os.path.join("profiles", "valu_issue_model.json")
     try:
-        model = json.load(open(os.path.join(ROOT, model_src)))["configs"].get(args.config)
+        entries = json.load(open(os.path.join(ROOT, model_src)))["configs"]
+        model = entries.get(args.config)
+        if model is None:  # another config that runs the same kernel instantiation (C2, C3r: the C3 kernel)
+            same = [e for e in entries.values()
+                    if (e.get("D"), e.get("dtype"), e.get("kernel_kind")) == (D, dtype_name, kname)]
+            model = same[0] if same else None
     except Exception:
         model = None
     roof = {"bound": "valu",
