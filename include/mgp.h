@@ -161,7 +161,9 @@ const char* mgp_build_arch(void);
 
 /* ---- matrix-free kernel products --------------------------
  * out[N,R] = k(X,Z) V      replaces Kuf(...)^T @ a, cggp/models.py:334,351 (and :273,:157)
- * V, out layouts given by v_layout / out_layout (MGP_COLS: [M,R]/[N,R]; MGP_ROWS: [R,M]/[R,N]). */
+ * V, out layouts given by v_layout / out_layout (MGP_COLS: [M,R]/[N,R]; MGP_ROWS: [R,M]/[R,N]).
+ * An empty contraction set (M = 0 here, N = 0 in mgp_kmn_matvec: no inducing points / a rank without rows) is not an
+ * error: the output is written as zeros, what the reference's dense [B,0].[0,R] product gives. */
 int mgp_knm_matvec(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
                    int64_t M, const void* V, int32_t R, int v_layout, void* out, int out_layout);
 /* out[M,R] = k(Z,X) W = K_nm^T W   (W [N,R]); deterministic two-stage reduction over row
