@@ -1,7 +1,8 @@
 """Predictive mean / variance -- the quantity the north star's 1e-6 tolerance is stated on
 (`cggp/models.py:324-354`) -- at the inducing-set size of every BASELINE.json config:
 
-* C2 (N=100 000, D=8, M=2048) and C3 (N=2^20, D=8, M=4096): `CGGP.predict_f` on a 256-row batch against
+* C2 (N=100 000, D=8, M=2048), C3 (N=2^20, D=8, M=4096) and C5's shape (N=2^20, D=32, M=4096, Matern-3/2; the
+  lengthscale raised to sqrt(D) so that the system is not numerically diagonal): `CGGP.predict_f` on a 256-row batch against
   `oracle/models.py:CGGP.predict_f` given the SAME `pseudo_u` / `cluster_counts`
     - near the reference recurrence's guard floor (thr 1e-15, cap 4M): 1e-6 on the mean, 1e-6 * k** on the
       variance, against the oracle's Cholesky twin (`ClusterGP.predict_f`, `models.py:250-276`) and, at C2, also
@@ -43,10 +44,14 @@ def _cdgp(cfg):
     N, D, M, dt, kname = synthetic.CONFIGS[cfg]
     syn = synthetic.make_inputs(N, D, M, dt)
     X, y, Z = (torch.from_numpy(a).to(dev()) for a in (syn.X, syn.y, syn.Z))
-    kern = kernels.SquaredExponential(1.0, [1.0] * D)
+    # C5's kernel is Matern-3/2 in D = 32; its lengthscale is set to sqrt(D) here so that neighbouring points
+    # correlate (with l = 1 in 32 dimensions k(x, z) ~ 1e-5 off the diagonal and Kmm + Lambda is numerically diagonal:
+    # nothing for CG or the variance to do)
+    ls = 1.0 if kname == "se" else float(np.sqrt(D))
+    kern = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname](1.0, [ls] * D)
     m = CGGP(kern, 0.1, Z, ConjugateGradient(1e-6), num_probes=None, num_data=N)
     assign_inducing_parameters(m, *oips_update_inducing_parameters(m, (X, y), Z))
-    ko = ok.Kernel(kname, 1.0, np.ones(D))
+    ko = ok.Kernel(kname, 1.0, ls * np.ones(D))
     u, counts = m.pseudo_u.cpu().numpy(), m.cluster_counts.cpu().numpy()
     assert counts.sum() == N and counts.min() >= 1
     # prediction rows: a mix of training rows (coincident with some inducing points) and perturbed ones
@@ -58,7 +63,7 @@ def _cdgp(cfg):
     return syn, m, ko, u, counts, Xs
 
 
-@pytest.fixture(scope="module", params=["C2", "C3"])
+@pytest.fixture(scope="module", params=["C2", "C3", "C5"])
 def cdgp(request):
     out = _cdgp(request.param)
     yield (request.param,) + out
