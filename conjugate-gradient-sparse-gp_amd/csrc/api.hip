@@ -56,6 +56,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (tf) h->tri_form = atoi(tf);
   const char* fa = getenv("MGP_FUSE_AGREE");
   if (fa) h->fuse_agree = atoi(fa);
+  const char* kta = getenv("MGP_KDENSE_TA");
+  if (kta && (atoi(kta) == 16 || atoi(kta) == 64)) h->kdense_ta = atoi(kta);
   const char* cd1 = getenv("MGP_CG_DENSE1");
   if (cd1) h->cg_dense1 = atoi(cd1);
   const char* tm = getenv("MGP_TRI_MIN_N");

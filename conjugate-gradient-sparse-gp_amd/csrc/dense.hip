@@ -16,12 +16,15 @@
 namespace {
 
 // ------------------------------------------------------------------ k_dense
-template <typename T, int DP, int KIND>
+// TA rows of A per block (staged in LDS, read back as wave-uniform broadcasts), one column of B per thread (held in
+// registers).  A thread loads its B point once per block, so TA sets how often B is re-read from L2: at D = 32 a
+// point is 32 loads for TA pairs -- with TA = 16 the C5 contraction's panel kernel read 4.3 GB of B through L2 to
+// write 2.1 GB (2.13 ms per panel); TA = 64 there.
+template <typename T, int DP, int KIND, int TA>
 __global__ __launch_bounds__(256) void k_dense_kernel(const T* __restrict__ A, long na,
                                                       const T* __restrict__ B, long nb, T* __restrict__ out,
                                                       long ld, int D, SweepParams prm, T jitter,
                                                       const T* __restrict__ diag_add) {
-  constexpr int TA = 16;  // rows of A per block
   constexpr int PS = (DP + 1 + 1) & ~1;
   __shared__ __attribute__((aligned(16))) T tile[TA * PS];
   const int t = threadIdx.x;
@@ -74,10 +77,18 @@ __global__ __launch_bounds__(256) void k_dense_kernel(const T* __restrict__ A, l
 template <typename T, int KIND>
 int k_dense_dp(mgp_handle* h, const SweepParams& prm, int D, const T* A, long na, const T* B, long nb, T* out,
                long ld, T jitter, const T* diag_add) {
-  dim3 grid((unsigned)((nb + 255) / 256), (unsigned)((na + 15) / 16));
-#define MGP_KD(DPV)                                                                                         \
-  hipLaunchKernelGGL((k_dense_kernel<T, DPV, KIND>), grid, dim3(256), 0, h->stream, A, na, B, nb, out, ld, D, \
-                     prm, jitter, diag_add)
+  // rows of A per block: 64 when a B point is expensive to load (D > 8) or there are enough blocks anyway
+  const int ta = (h->kdense_ta > 0) ? h->kdense_ta : ((D > 8 && na >= 64) ? 64 : 16);
+  dim3 grid((unsigned)((nb + 255) / 256), (unsigned)((na + ta - 1) / ta));
+#define MGP_KD(DPV)                                                                                                  \
+  do {                                                                                                               \
+    if (ta == 64)                                                                                                    \
+      hipLaunchKernelGGL((k_dense_kernel<T, DPV, KIND, 64>), grid, dim3(256), 0, h->stream, A, na, B, nb, out, ld, D, \
+                         prm, jitter, diag_add);                                                                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_dense_kernel<T, DPV, KIND, 16>), grid, dim3(256), 0, h->stream, A, na, B, nb, out, ld, D, \
+                         prm, jitter, diag_add);                                                                     \
+  } while (0)
   if (D <= 2) MGP_KD(2);
   else if (D <= 4) MGP_KD(4);
   else if (D <= 8) MGP_KD(8);

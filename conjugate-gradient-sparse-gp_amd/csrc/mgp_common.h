@@ -85,6 +85,7 @@ struct mgp_handle {
   // iteration with no hand-off inside either (cg_dense1.hip), 0 = product (tile kernel + slot reduce) + fused
   // update launch (MGP_CG_DENSE1)
   int cg_dense1 = 1;
+  int kdense_ta = 0;  // rows of A per block of k_dense_kernel: 0 = by shape (16, or 64 at D > 8), else 16 or 64 (MGP_KDENSE_TA)
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
   int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
   int skinny_stagger = 0;  // experiment (MGP_SKINNY_STAGGER): start-up delay units between workgroup phases
