@@ -23,9 +23,11 @@ can be recomputed from this line and ONE committed file, profiles/valu_issue_mod
 
 import argparse
 import ctypes
+import datetime
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +61,32 @@ def _pct(a):
     return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90))}
 
 
+class Watchdog:
+    """Bounded waits for the N > 1 launch: a rank that is still in `stage` when the deadline passes prints where it
+    is and leaves with a non-zero status (os._exit: no exec, no re-launch -- the process has touched the GPU), so a
+    bootstrap or collective problem of a node shows up as a failed run, never as a hang."""
+
+    def __init__(self, rank):
+        self.rank, self.stage, self.deadline, self.lock = rank, "start", None, threading.Lock()
+        self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self.thread.start()
+
+    def arm(self, stage, seconds):
+        with self.lock:
+            self.stage, self.deadline = stage, (time.monotonic() + seconds if seconds and seconds > 0 else None)
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                stage, deadline = self.stage, self.deadline
+            if deadline is not None and time.monotonic() > deadline:
+                try:
+                    os.write(2, f"[bench.py] rank {self.rank}: timed out in stage '{stage}' -- exiting 124\n".encode())
+                finally:
+                    os._exit(124)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +108,10 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default): the config's N is the TOTAL row count, sharded over the ranks -- the "
                          "size BASELINE.json's metric is quoted on; weak: every rank holds the config's N rows")
+    ap.add_argument("--bootstrap-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the rendezvous + RCCL communicator creation may take before the rank exits 124")
+    ap.add_argument("--run-timeout", type=float, default=1200.0,
+                    help="N > 1: seconds everything after the bootstrap may take before the rank exits 124 (0 = no limit)")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout (RCCL prints a version banner there): park fd 1 on stderr
@@ -102,15 +134,19 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    dog = Watchdog(rank) if world > 1 else None
     if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if dog:
+            dog.arm("rendezvous / init_process_group", args.bootstrap_timeout)
+        tmo = datetime.timedelta(seconds=max(30.0, args.bootstrap_timeout))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     from cggp import _hip, kernels, ops, parallel, synthetic
     from cggp.conjugate_gradient import SgprNormalOperator, conjugate_gradient
@@ -133,7 +169,14 @@ def main():
     kern = {"se": kernels.SquaredExponential, "matern32": kernels.Matern32}[kname](
         variance=syn.variance, lengthscales=syn.lengthscales)
     spec = kern.spec(D)
-    allreduce = parallel.make_allreduce(force=args.force_collective)
+    if dog:
+        dog.arm("libmgp RCCL communicator (mgp_comm_init_rank)", args.bootstrap_timeout)
+    allreduce = parallel.make_allreduce(force=args.force_collective, timeout_s=0.75 * args.bootstrap_timeout)
+    if dog:
+        dog.arm("run", args.run_timeout)
+    rccl_ranks, collective = allreduce.describe() if allreduce is not None else (1, "none (one rank)")
+    if world > 1 and rccl_ranks != world:
+        raise SystemExit(f"the collective spans {rccl_ranks} ranks but WORLD_SIZE={world}")
     kmm_rows = parallel.kmm_slab(M, emu, 0) if emu else parallel.kmm_slab(M)
     op = SgprNormalOperator(kern, X, Z, syn.noise_variance, jitter=1e-6, allreduce=allreduce, max_rhs=1,
                             kmm_rows=kmm_rows)
@@ -441,10 +484,11 @@ def main():
                        "kmm_rows_of_this_rank": [int(kmm_rows[0]), int(kmm_rows[1])],
                        "emulated_world": emu or None,
                        "parallelism": f"rows of X sharded over {emu or world} GPU(s), one all-reduce of [1,M]+1 per step",
-                       "collective": ("none (one rank)" if allreduce is None else
-                                      "libmgp ncclAllReduce on the solve's stream (mgp_operator.comm)"
-                                      if getattr(allreduce, "comm", None) is not None else
-                                      "callback hook -> torch.distributed (" + args.backend + ")")},
+                       "collective": collective,
+                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks_note": "mgp_comm_size of libmgp's own communicator when the collective is native, "
+                                          "torch.distributed's group size when it goes through the callback hook",
+                       "native_comm_error": getattr(allreduce, "native_error", None)},
             "roofline": roof,
             "cpu_baseline": cpu,
             # "converging to residual <= 1e-6" (north star): the reference recurrence (identity preconditioner)

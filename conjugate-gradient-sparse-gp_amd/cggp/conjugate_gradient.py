@@ -414,9 +414,11 @@ class SubsampledNormalPreconditioner(DensePreconditioner):
         X, Z = operator.X, operator.Z
         M, N_local = Z.shape[0], X.shape[0]
         world = 1
-        if operator.allreduce is not None:
-            import torch.distributed as dist
-            world = dist.get_world_size() if dist.is_initialized() else 1
+        if operator.allreduce is not None:  # the ranks the operator's own exchange spans (it may be a sub-group)
+            world = int(getattr(operator.allreduce, "world_size", 0) or 0)
+            if world < 1:
+                import torch.distributed as dist
+                world = dist.get_world_size() if dist.is_initialized() else 1
         n_s = min(N_local, max(1, (int(rows_per_inducing) * M + world - 1) // world))
         # shards hold different rows, so one seed gives independent samples per rank
         gen = torch.Generator(device=X.device).manual_seed(int(seed))

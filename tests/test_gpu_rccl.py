@@ -128,7 +128,7 @@ _FALLBACK_WORKER = textwrap.dedent("""
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     class Broken:
-        def __init__(self, group=None, device=None):
+        def __init__(self, group=None, device=None, timeout_s=None):
             raise RuntimeError("communicator bootstrap failed (scripted)")
     parallel.Communicator = Broken
     ar = parallel.make_allreduce(force=True)
