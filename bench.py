@@ -212,8 +212,8 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- dominant kernel: the fused sweep (K_nm.p and K_mn.u are the same kernel symbol).  A second pass of the
-    # same K steps with HIP events bracketing every launch of it on the solve's stream, while one resident wave
-    # samples the shader clock (started first, so that it holds its slot before the sweeps fill the chip)
+    # same K steps with HIP events bracketing every launch of it on the solve's stream; 16 workgroups of every
+    # bracketed launch stamp the shader-clock and constant counters (mgp_profile_read_clocks)
     hd = _hip.get_handle(dev)
     clock = None
     hd.check(hd.lib.mgp_profile_enable(hd.h, 1))
@@ -246,9 +246,17 @@ def main():
 
     # PMC model of this config's kernel instantiation (committed; tools/make_valu_model.py builds it from the
     # rocprofv3 --pmc passes of tools/pmc_sweep.sh)
-    model, model_src = None, os.path.join("profiles", "valu_issue_model.json")
+    model, model_src, model_stale = None, os.path.join("profiles", "valu_issue_model.json"), None
     try:
-        entries = json.load(open(os.path.join(ROOT, model_src)))["configs"]
+        model_file = json.load(open(os.path.join(ROOT, model_src)))
+        entries = model_file["configs"]
+        # the counters belong to ONE version of the kernel source: a later edit makes `frac` stale
+        import hashlib
+        model_stale = []
+        for path, sha in (model_file.get("measured_sources") or {}).items():
+            data = open(os.path.join(ROOT, path), "rb").read()
+            if hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest() != sha:
+                model_stale.append(path)
         model = entries.get(args.config)
         if model is None:  # another config that runs the same kernel instantiation (C2, C3r: the C3 kernel)
             same = [e for e in entries.values()
@@ -275,6 +283,10 @@ def main():
                          "active_valu_quadcycles_per_wave_pair": q,
                          "valu_instructions_per_pair": model.get("valu_instructions_per_pair"),
                          "pmc_source": model.get("source"), "kernel": model.get("kernel"),
+                         "stale": bool(model_stale),
+                         "stale_note": ("kernel sources edited since the PMC passes: " + ", ".join(model_stale)
+                                        if model_stale else "the PMC passes ran on the kernel sources of this tree "
+                                        "(git blob hashes in the model file)" if model_stale is not None else None),
                          "recompute": "frac = pairs_per_launch / 64 * active_valu_quadcycles_per_wave_pair * 4 / "
                                       "(1024 * 2.4e9) / (avg_launch_ms * 1e-3)"}
         if clock:

@@ -112,7 +112,7 @@ extern "C" size_t mgp_workspace_bytes(const mgp_handle* h) {
   if (h->pool) return h->pool_used;
   // 256 bytes of alignment slack per arena, as a fixed pool would spend
   return h->ws_bytes + h->cg_bytes + h->opws_bytes + h->gen_bytes + h->pack[0].bytes + h->pack[1].bytes +
-         h->tri_tab_bytes + 7 * 256;
+         h->tri_tab_bytes + h->prof_clk_bytes + 8 * 256;
 }
 
 extern "C" int mgp_destroy(mgp_handle* h) {
@@ -128,8 +128,8 @@ extern "C" int mgp_destroy(mgp_handle* h) {
     if (h->tri_tab) (void)hipFree(h->tri_tab);
     for (auto& ps : h->pack)
       if (ps.buf) (void)hipFree(ps.buf);
+    if (h->prof_clk) (void)hipFree(h->prof_clk);
   }
-  if (h->prof_clk) (void)hipFree(h->prof_clk);
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);
@@ -152,9 +152,10 @@ extern "C" const char* mgp_last_error(mgp_handle* h) { return h ? h->err : "inva
 
 extern "C" int mgp_profile_enable(mgp_handle* h, int on) {
   if (!h) return MGP_E_BADARG;
-  if (on) {  // clock stamps of the profiled launches: a fixed block (bench-only: allocated outside the workspace)
+  if (on) {  // clock stamps of the profiled launches: one more arena of the workspace (4 MB) -- with a fixed pool
+             // (mgp_create_ex) it comes out of the pool or the call returns MGP_E_NOMEM; nothing is allocated then
     const size_t bytes = (size_t)MGP_PROF_CLK_LAUNCHES * MGP_PROF_CLK_WORDS * sizeof(unsigned long long);
-    if (!h->prof_clk) MGP_HIP(h, hipMalloc(&h->prof_clk, bytes));
+    MGP_TRY(mgp_reserve(h, &h->prof_clk, &h->prof_clk_bytes, bytes));
     MGP_HIP(h, hipMemsetAsync(h->prof_clk, 0, bytes, h->stream));
     h->prof_clk_launches = 0;
   }

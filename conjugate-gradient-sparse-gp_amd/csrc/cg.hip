@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const T* __restrict__ b, c
 // `force` bypasses the gate (start-up of the dense-preconditioner path).
 // Block size: 256 threads per right-hand side up to n = 8192, 1024 beyond (the fused kernel covers n <= 8192; one
 // 256-thread workgroup per right-hand side was a cliff for larger systems).
-template <typename T>
-__global__ __launch_bounds__(1024) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
+// NTB is the launch bound AND the launch size (256 or 1024): small systems keep the register budget of a 256-thread
+// workgroup (one 1024-thread bound capped it for every launch).
+template <typename T, int NTB>
+__global__ __launch_bounds__(NTB) void cg_update_kernel(const CgCtrl* __restrict__ ctrl, T* __restrict__ v,
                                                         T* __restrict__ r, T* __restrict__ p,
                                                         T* __restrict__ z, const T* __restrict__ ap,
                                                         T* __restrict__ rz, int* __restrict__ over,
@@ -538,6 +540,13 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   void* d1_arena = (void*)(((uintptr_t)(ctrl + 1) + 15) & ~(uintptr_t)15);
   hipStream_t s = h->stream;
   const unsigned upd_threads = n > 8192 ? 1024u : 256u;  // generic update kernel: threads per right-hand side
+#define MGP_UPDATE_LAUNCH(...)                                                                                   \
+  do {                                                                                                           \
+    if (upd_threads == 1024u)                                                                                    \
+      hipLaunchKernelGGL((cg_update_kernel<T, 1024>), dim3((unsigned)Bt), dim3(1024), 0, s, __VA_ARGS__);        \
+    else                                                                                                         \
+      hipLaunchKernelGGL((cg_update_kernel<T, 256>), dim3((unsigned)Bt), dim3(256), 0, s, __VA_ARGS__);          \
+  } while (0)
   // z = M^-1 r for the preconditioners applied outside the update kernels
   auto external_z = [&](const int* gate) -> int {
     if (cb) {
@@ -571,7 +580,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, av, r, tot, 1);
     MGP_LAUNCH_CHECK(h);
     MGP_TRY(external_z(nullptr));
-    hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz, over,
+    MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz, over,
                        err_out, n, (T)thr, (T)min_float, pc, 5, 1);
     MGP_LAUNCH_CHECK(h);
   }
@@ -653,25 +662,25 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
         continue;  // bookkeeping done inside the kernel
       } else if (!reset) {
         if (!dense_pre) {
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
+          MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 0, 0);
         } else {
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
+          MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 3, 0);
           MGP_LAUNCH_CHECK(h);
           MGP_TRY(external_z(&ctrl->active));
-          hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
+          MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz,
                              over, err_out, n, (T)thr, (T)min_float, pc, 4, 0);
         }
       } else {
-        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
+        MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, 1, 0);
         MGP_LAUNCH_CHECK(h);
         MGP_TRY(apply_operator<T>(h, op, V, Bt, ap, &ctrl->active));
         hipLaunchKernelGGL((cg_residual_kernel<T>), dim3(nblk(tot)), dim3(256), 0, s, ctrl, B, ap, r, tot, 0);
         MGP_LAUNCH_CHECK(h);
         if (dense_pre) MGP_TRY(external_z(&ctrl->active));
-        hipLaunchKernelGGL((cg_update_kernel<T>), dim3((unsigned)Bt), dim3(upd_threads), 0, s, ctrl, V, r, p, z, ap, rz,
+        MGP_UPDATE_LAUNCH(ctrl, V, r, p, z, ap, rz,
                            over, err_out, n, (T)thr, (T)min_float, pc, dense_pre ? 5 : 2, 0);
       }
       MGP_LAUNCH_CHECK(h);
@@ -699,6 +708,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     stats->converged = any ? 0 : 1;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+#undef MGP_UPDATE_LAUNCH
   return MGP_OK;
 }
 

@@ -279,11 +279,11 @@ extern "C" int mgp_segment_sums(mgp_handle* h, int dtype, const int64_t* order, 
 extern "C" int mgp_nearest_center(mgp_handle* h, const mgp_kernel* k, int dist_type, const void* X, int64_t N,
                                   const void* Z, int64_t M, int64_t* idx, void* best) {
   MGP_TRY(mgp_check_kernel(h, k));
-  MGP_TRY(mgp_check_fused_dim(h, k, "nearest_center"));
   if (dist_type < 0 || dist_type > 3) return mgp_fail(h, MGP_E_BADARG, "bad dist_type %d", dist_type);
   if (N < 0 || M <= 0 || M > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "nearest_center needs N >= 0 and 0 < M < 2^31");
   if (N == 0) return MGP_OK;
   if (!X || !Z || !idx) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (k->D > MGP_FUSED_MAX_D) return mgp_nearest_generic(h, k, dist_type, X, N, Z, M, idx, best);  // generic.hip
   if (k->dtype == MGP_F64)
     return nearest_t<double>(h, k, dist_type, (const double*)X, N, (const double*)Z, M, (long*)idx, (double*)best);
   return nearest_t<float>(h, k, dist_type, (const float*)X, N, (const float*)Z, M, (long*)idx, (float*)best);

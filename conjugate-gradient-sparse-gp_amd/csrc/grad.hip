@@ -163,13 +163,14 @@ int vjp_t(mgp_handle* h, const mgp_kernel* k, const T* A, long na, const T* B, l
 extern "C" int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B,
                                int64_t nb, const void* G, int64_t ldg, double* dvariance, double* dlengthscales) {
   MGP_TRY(mgp_check_kernel(h, k));
-  MGP_TRY(mgp_check_fused_dim(h, k, "k_dense_vjp"));
   if (!dvariance || !dlengthscales) return mgp_fail(h, MGP_E_BADARG, "NULL output");
   *dvariance = 0.0;
   for (int d = 0; d < k->D; ++d) dlengthscales[d] = 0.0;
   if (na < 0 || nb < 0 || ldg < nb) return mgp_fail(h, MGP_E_SHAPE, "k_dense_vjp: bad shape");
   if (na == 0 || nb == 0) return MGP_OK;
   if (!A || !B || !G) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
+  if (k->D > MGP_FUSED_MAX_D)  // generic.hip: dimensions staged through LDS
+    return mgp_k_dense_vjp_generic(h, k, A, na, B, nb, G, ldg, dvariance, dlengthscales);
   if (k->dtype == MGP_F64)
     return vjp_t<double>(h, k, (const double*)A, na, (const double*)B, nb, (const double*)G, ldg, dvariance,
                          dlengthscales);

@@ -64,7 +64,7 @@ struct mgp_handle {
   // and the younger fills its stalls, so each CU ends with one workgroup running alone at ~0.82 of the rate of two --
   // the shorter the workgroups, the shorter that tail (C3: 4.75 -> 4.66 ms per CG step against 8)
   int sweep_target_per_cu = 16;
-  int sweep_chunk_gran = 256;  // streamed points per chunk are a multiple of this in the fast kernel (MGP_SWEEP_GRAN: 64, 128, 256)
+  int sweep_chunk_gran = 0;  // fast kernel: streamed points per chunk are a multiple of this (MGP_SWEEP_GRAN: 64, 128, 256); 0 = the tile size TB of the shape
   int sweep_fast_rpt32 = 2;  // the same for 16 < D <= 32: 2 (2 waves/SIMD) or 1 (4 waves/SIMD) -- MGP_SWEEP_RPT32
   int sweep_fast_rpt_rc = 2;  // owned points per lane with 2 or 4 right-hand sides at D <= 8 (2 or 3) -- MGP_SWEEP_RPT_RC
   int sweep_fast_rpt = 4;  // owned points per lane of the fast kernel: 4 (4 waves/SIMD), 3 (5), 2 (8) -- MGP_SWEEP_RPT
@@ -113,6 +113,7 @@ struct mgp_handle {
   size_t prof_used = 0;
   // bench-only: clock stamps of the profiled sweep launches (mgp_profile_read_clocks): 16 slots of 4 words each
   void* prof_clk = nullptr;
+  size_t prof_clk_bytes = 0;
   size_t prof_clk_launches = 0;
 };
 
@@ -279,13 +280,6 @@ inline int mgp_check_kernel(mgp_handle* h, const mgp_kernel* k) {
   return MGP_OK;
 }
 
-// entry points without a generic-D form yet
-inline int mgp_check_fused_dim(mgp_handle* h, const mgp_kernel* k, const char* what) {
-  if (k->D > MGP_FUSED_MAX_D)
-    return mgp_fail(h, MGP_E_SHAPE, "%s supports D <= %d (got %d)", what, MGP_FUSED_MAX_D, k->D);
-  return MGP_OK;
-}
-
 // Scaled kernel parameters passed by value to device code.
 struct SweepParams {
   double inv_ls[MGP_FUSED_MAX_D];  // c_kind / lengthscale_d (fused kernels only: D <= 32)
@@ -326,6 +320,12 @@ int mgp_k_dense_generic(mgp_handle* h, const mgp_kernel* k, const void* A, int64
                         void* out, int64_t ld, double jitter, const void* diag_add, const int* gate);
 int mgp_sweep_generic(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
                       VecView W, int32_t R, VecViewMut out, double alpha, VecView addend, const int* gate);
+int mgp_nearest_generic(mgp_handle* h, const mgp_kernel* k, int dist_type, const void* X, int64_t N, const void* Z,
+                        int64_t M, int64_t* idx, void* best);
+int mgp_k_dense_vjp_generic(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, const void* B, int64_t nb,
+                            const void* G, int64_t ldg, double* dvariance, double* dlengthscales);
+int mgp_kmn_sq_colsum_generic(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z, int64_t M,
+                              void* out);
 int mgp_gemm_nt(mgp_handle* h, int dtype, const void* P, int64_t ldp, int64_t m, const void* A, int64_t lda, int64_t n,
                 int64_t K, void* out, int64_t ldo, int accumulate, const int* gate);
 int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long na, const double* B, long nb,

@@ -860,8 +860,9 @@ int launch_sweep(mgp_handle* h, const SweepParams& prm, int D, const T* A, long 
   const long nosplit = frpt ? (h->nosplit_per_cu > 8 ? h->nosplit_per_cu : 8) : h->nosplit_per_cu;
   long nchunks = nblk * (fnt / kThreads) >= nosplit * h->num_cus ? 1 : (target + nblk - 1) / nblk;
   // chunk granularity: the LDS-tile kernels stream whole tiles of TB points; the fast kernel has no tile and takes
-  // any even count (MGP_SWEEP_GRAN, default TB)
-  const long gran = frpt ? (long)h->sweep_chunk_gran : (long)TB;
+  // any even count: MGP_SWEEP_GRAN = 64 / 128 / 256 overrides it for A/B runs, the default (0) is TB -- 256 points at
+  // D <= 8, 128 at D <= 16, 64 at D <= 32 -- i.e. the chunking every committed measurement ran with
+  const long gran = (frpt && h->sweep_chunk_gran > 0) ? (long)h->sweep_chunk_gran : (long)TB;
   const long max_chunks = (nb + gran - 1) / gran;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
@@ -1137,7 +1138,6 @@ int mgp_sweep(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t na, con
 extern "C" int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void* X, int64_t N, const void* Z,
                                  int64_t M, void* out) {
   MGP_TRY(mgp_check_kernel(h, k));
-  MGP_TRY(mgp_check_fused_dim(h, k, "kmn_sq_colsum"));
   if (N < 0 || M < 0) return mgp_fail(h, MGP_E_SHAPE, "negative size");
   if (M == 0) return MGP_OK;
   if (!Z || !out || (N > 0 && !X)) return mgp_fail(h, MGP_E_BADARG, "NULL data pointer");
@@ -1145,6 +1145,7 @@ extern "C" int mgp_kmn_sq_colsum(mgp_handle* h, const mgp_kernel* k, const void*
     MGP_HIP(h, hipMemsetAsync(out, 0, (size_t)M * mgp_elem(k->dtype), h->stream));
     return MGP_OK;
   }
+  if (k->D > MGP_FUSED_MAX_D) return mgp_kmn_sq_colsum_generic(h, k, X, N, Z, M, out);  // generic.hip: explicit panels
   if (k->dtype == MGP_F64)
     return sweep_sq_kind<double>(h, k, (const double*)Z, M, (const double*)X, N, (const double*)h->ones,
                                  (double*)out);

@@ -33,9 +33,10 @@ extern "C" {
 
 #define MGP_VERSION 210 /* 0.2.1: + mgp_profile_read_clocks (0.2.0: mgp_comm, mgp_operator.comm, mgp_create_ex) */
 #define MGP_MAX_D 512      /* input dimensions the library accepts (capacity of mgp_kernel) */
-#define MGP_FUSED_MAX_D 32 /* up to here the fused register-resident sweeps run; above, products go through
-                            * row-chunked explicit kernel panels + the NT GEMM (the reference's dense form);
-                            * nearest-centre, the k^2 column sum and the kernel VJP are fused-only for now */
+#define MGP_FUSED_MAX_D 32 /* up to here the fused register-resident kernels run; above, every entry point takes
+                            * the generic route (csrc/generic.hip): products through row-chunked explicit kernel
+                            * panels + the NT GEMM (the reference's dense form), nearest-centre, the kernel VJP
+                            * and the k^2 column sum tile by tile with the dimensions staged through LDS */
 
 enum { MGP_OK = 0, MGP_E_BADARG = -1, MGP_E_SHAPE = -2, MGP_E_DTYPE = -3, MGP_E_HIP = -4,
        MGP_E_COMM = -5, MGP_E_NOMEM = -6 };
@@ -264,7 +265,9 @@ int mgp_k_dense_vjp(mgp_handle* h, const mgp_kernel* k, const void* A, int64_t n
 /* ---- measurement (bench.py): HIP events around every launch of the fused sweep kernel ------
  * While enabled, each sweep launch is bracketed by two events on the handle's stream;
  * mgp_profile_read synchronises the stream, returns the number of bracketed launches and the
- * sum of their durations in milliseconds, and resets the counters. */
+ * sum of their durations in milliseconds, and resets the counters.  Enabling reserves a 4 MB block for
+ * the clock stamps below as one more arena of the workspace: counted by mgp_workspace_bytes, taken from
+ * the fixed pool of mgp_create_ex (MGP_E_NOMEM if it does not fit) -- no allocation outside it. */
 int mgp_profile_enable(mgp_handle* h, int on);
 int mgp_profile_read(mgp_handle* h, int64_t* launches, double* total_ms);
 /* as mgp_profile_read, but one duration per bracketed launch (the first `capacity` of them) so the

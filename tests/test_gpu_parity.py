@@ -264,8 +264,9 @@ def test_generic_dimension_path(name, D):
     rhs = rng.standard_normal((M, 2))
     sol = ConjugateGradient(1e-14, max_iterations=3000)(op, T(rhs))
     assert relerr(sol, np.linalg.solve(S, rhs)) < 1e-6
-    with pytest.raises(RuntimeError, match="D <= 32"):
-        ops.nearest_center(spec, T(X), T(Z))
+    # the k^2 column sum (diag of K_mn K_nm) above the fused limit: explicit panels, ordered partial sums
+    assert relerr(ops.kmn_sq_colsum(spec, T(X), T(Z)), np.sum(K * K, axis=0)) < 1e-12
+    assert relerr(op.diag(), np.diag(S)) < 1e-9
 
 
 # ------------------------------------------------------------------ dense K
@@ -1000,6 +1001,58 @@ def test_nearest_center(dist):
     assert np.mean(idx == ref_idx) > 0.999
     assert np.max(np.abs(chosen - d_all.min(1))) < 1e-10
     assert relerr(best, chosen) < 1e-9
+
+
+@pytest.mark.parametrize("dist", ["sqeuclidean", "euclidean", "covariance", "correlation"])
+@pytest.mark.parametrize("D", [33, 77, 90])
+def test_nearest_center_any_dimension(dist, D):
+    """Row F1 above the fused limit (the reference's `buzz` has D = 77, `song` D = 90, cli_utils.py:72-86; its
+    assignment is dimension-free, optimize.py:41-98): the index sequence is the oracle's, exactly."""
+    from cggp import ops
+    N, M = 3001, 70  # neither a multiple of the 64-wide tiles
+    k, ko = make_kernel("matern32", D)
+    for d in range(D):
+        k.lengthscales[d] *= np.sqrt(D)
+    ko.lengthscales = ko.lengthscales * np.sqrt(D)
+    X, Z = points(N, M, D)
+    Z[:5] = X[:5]  # coincident points: distance exactly 0 for `euclidean` (norm of differences)
+    idx, best = ops.nearest_center(k.spec(D), T(X), T(Z), distance_type=dist)
+    idx = idx.cpu().numpy()
+    if dist == "sqeuclidean":
+        d_all = ok.square_distance(Z, X).T
+    else:
+        fn = od.create_distance_fn(ko, dist)
+        d_all = fn((Z[None, :, :], X[:, None, :]))
+    assert np.array_equal(idx, np.argmin(d_all, axis=1))
+    chosen = d_all[np.arange(N), idx]
+    assert np.max(np.abs(best.cpu().numpy() - chosen)) < 1e-9 * max(1.0, np.max(np.abs(chosen)))
+    if dist == "euclidean":
+        assert np.all(best.cpu().numpy()[:5] == 0.0)
+    # ties: duplicated centres -> the FIRST index wins (argmin semantics)
+    Zd = np.vstack([Z, Z])
+    idx2 = ops.nearest_center(k.spec(D), T(X), T(Zd), distance_type=dist, return_distance=False).cpu().numpy()
+    assert np.array_equal(idx2, idx)
+
+
+def test_nearest_center_any_dimension_fp32_and_the_update_functions():
+    from cggp import kernels, ops
+    from cggp.models import ClusterGP
+    from cggp.optimize import kmeans_update_inducing_parameters, oips_update_inducing_parameters
+    D, N, M = 77, 5000, 100
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((N, D))
+    Z = X[rng.choice(N, M, replace=False)]
+    y = np.sin(X[:, :3]).sum(1, keepdims=True)
+    k = kernels.SquaredExponential(1.0, [np.sqrt(D)] * D)
+    ref_idx = oc.nearest_centre_sqdist(Z, X)
+    i32 = ops.nearest_center(k.spec(D), T(X, torch.float32), T(Z, torch.float32), return_distance=False).cpu().numpy()
+    assert np.mean(i32 == ref_idx) > 0.995  # fp32 rounding moves only numerical near-ties
+    u, counts = oc.cluster_stats(ref_idx, y, M)
+    m = ClusterGP(k, 0.1, T(Z))
+    _, means, c = oips_update_inducing_parameters(m, (T(X), T(y)), T(Z))
+    assert relerr(means, u) < 1e-12 and relerr(c, counts) == 0.0
+    _, means_k, c_k = kmeans_update_inducing_parameters(m, (T(X), T(y)), "euclidean", T(Z))
+    assert relerr(c_k, counts) == 0.0 and relerr(means_k, u) < 1e-12
 
 
 def test_cluster_stats_and_update():

@@ -43,6 +43,78 @@ def test_k_dense_vjp_matches_finite_differences(name, D):
         assert abs(dls[d] - fd) < 2e-6 * max(1.0, abs(fd)), (d, dls[d], fd)
 
 
+@pytest.mark.parametrize("name", KINDS)
+@pytest.mark.parametrize("D", [33, 77, 90])
+def test_k_dense_vjp_any_dimension(name, D):
+    """Row F2 above the fused limit (D = 77 / 90 are the reference's `buzz` / `song`, cli_utils.py:72-86): the
+    tile-wise reduction of csrc/generic.hip against finite differences of the oracle's kernel, every lengthscale."""
+    from cggp import ops
+    rng = np.random.default_rng(0)
+    na, nb = 150, 70  # ragged against the 64-wide tiles
+    A, B = rng.standard_normal((na, D)), rng.standard_normal((nb, D)) + 0.3
+    B[:3] = A[:3]  # coincident pairs: the Matern floor (f' = 0 there)
+    G = rng.standard_normal((na, nb))
+    var, ls = 1.3, (rng.random(D) + 0.7) * np.sqrt(D)
+    spec = ops.KernelSpec(name, var, ls.tolist(), D)
+    dvar, dls = ops.k_dense_vjp(spec, T(A), T(B), T(G))
+    dls = np.asarray(dls)
+
+    def f(v, l):
+        k = ok.Kernel(name, v, l)
+        d = (A[:, None, :] - B[None, :, :]) / l  # direct differences: the derivative of the exact kernel
+        return float(np.sum(G * k.K_r2(np.sum(d * d, -1))))
+
+    h = 1e-6
+    assert abs(dvar - (f(var + h, ls) - f(var - h, ls)) / (2 * h)) < 1e-6 * max(1.0, abs(dvar))
+    scale = max(1.0, float(np.max(np.abs(dls))))
+    for d in range(D):
+        e = np.zeros(D)
+        e[d] = h * ls[d]
+        fd = (f(var, ls + e) - f(var, ls - e)) / (2 * h * ls[d])
+        assert abs(dls[d] - fd) < 2e-6 * scale, (d, dls[d], fd)
+    # strided G (a view into a wider matrix) and the fp32 instantiation
+    Gw = np.zeros((na, nb + 9))
+    Gw[:, :nb] = G
+    dvar_s, dls_s = ops.k_dense_vjp(spec, T(A), T(B), T(Gw)[:, :nb])
+    assert dvar_s == dvar and np.array_equal(np.asarray(dls_s), dls)
+    dvar32, dls32 = ops.k_dense_vjp(spec, T(A).float(), T(B).float(), T(G).float())
+    assert abs(dvar32 - dvar) < 2e-4 * max(1.0, abs(dvar)) and np.max(np.abs(np.asarray(dls32) - dls)) < 2e-4 * scale
+
+
+@pytest.mark.parametrize("D", [33, 77])
+def test_elbo_gradient_any_dimension(D):
+    """The ELBO gradient through CG with D > 32 inputs against finite differences of the oracle's Cholesky twin."""
+    from cggp import kernels
+    from cggp.conjugate_gradient import ConjugateGradient
+    from cggp.training import TrainableCGGP
+    name = "matern32"
+    X, y, Z, u, counts = _problem(name, D=D)
+    rng = np.random.default_rng(4)
+    var, ls, s2 = 1.2, (0.8 + 0.4 * rng.random(D)) * np.sqrt(D), 0.15
+    m = TrainableCGGP(kernels.Matern32(var, ls), s2, T(Z), ConjugateGradient(1e-15, max_iterations=5000),
+                      num_probes=None, pseudo_u=T(u), cluster_counts=T(counts), num_data=X.shape[0])
+    xb, yb = X[:100], y[:100]
+    e = m.elbo((T(xb), T(yb)))
+    e.backward()
+    sig = lambda p: torch.sigmoid(p.raw.detach())
+    g_var = float(m.kernel.variance_p.raw.grad / sig(m.kernel.variance_p))
+    g_ls = (m.kernel.lengthscales_p.raw.grad / sig(m.kernel.lengthscales_p)).numpy()
+
+    def twin(v, l, s):
+        t = om.ClusterGP(ok.Kernel(name, v, l), s, Z, pseudo_u=u, cluster_counts=counts, num_data=X.shape[0])
+        return float(t.elbo((xb, yb)))
+
+    h = 1e-5
+    fd_var = (twin(var + h, ls, s2) - twin(var - h, ls, s2)) / (2 * h)
+    assert abs(g_var - fd_var) < 1e-4 * max(1.0, abs(fd_var)), (g_var, fd_var)
+    scale = max(1.0, float(np.max(np.abs(g_ls))))
+    for d in (0, 1, D // 2, 32, D - 1):
+        dl = np.zeros(D)
+        dl[d] = h
+        fd = (twin(var, ls + dl, s2) - twin(var, ls - dl, s2)) / (2 * h)
+        assert abs(g_ls[d] - fd) < 1e-4 * scale, (d, g_ls[d], fd)
+
+
 def _problem(name, N=240, D=2, M=14, seed=1):
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((N, D))

@@ -9,11 +9,20 @@ Per config it keeps, as means over the K_nm.v and K_mn.u launches (tools/run_swe
   hbm_bytes_per_launch                 = (FETCH_SIZE * 2 + WRITE_SIZE) * 1024   (MI355X_MICROARCH.md: gfx950 correction)
 and the raw per-launch counter means (copied to profiles/<tag>_pmc_<config>.json by this script).
 """
-import json, os, subprocess, sys
+import hashlib, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "conjugate-gradient-sparse-gp_amd"))
 from cggp import synthetic  # noqa: E402
+
+MODEL_SOURCES = ("conjugate-gradient-sparse-gp_amd/csrc/sweep.hip", "conjugate-gradient-sparse-gp_amd/csrc/mgp_math.h")
+
+
+def git_blob_sha1(path):
+    """`git hash-object` of a file: the identifier of the kernel source the counters were taken with."""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
 
 tag = sys.argv[1]
 # the instantiation launch_sweep picks for each config (csrc/sweep.hip; rocprofv3 truncates the templated names)
@@ -24,7 +33,13 @@ out = {"what": "PMC model of the fused sweep per BASELINE config: VALU-busy quad
                "evaluations), from rocprofv3 --pmc passes (tools/pmc_sweep.sh; one counter set per pass) over "
                "tools/run_sweep.py.  bench.py: frac = pairs_per_launch / 64 * active_valu_quadcycles_per_wave_pair * 4 "
                "/ (1024 SIMDs * 2.4e9 Hz) / avg_launch_seconds.",
-       "round": tag, "configs": {}}
+       "round": tag,
+       "measured_sources": {p: git_blob_sha1(os.path.join(ROOT, p)) for p in MODEL_SOURCES},
+       "measured_sources_note": "git blob hashes of the files that define the sweep kernels' instruction mix when the PMC "
+                                "passes ran; bench.py reports a mismatch as roofline.model.stale and "
+                                "tests/test_bench_model.py fails on it: re-run tools/pmc_sweep.sh + this script after "
+                                "editing them",
+       "configs": {}}
 for arg in sys.argv[2:]:
     cfg, d = arg.split("=")
     N, D, M, dt, kname = synthetic.CONFIGS[cfg]
