@@ -60,6 +60,8 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (kta && (atoi(kta) == 16 || atoi(kta) == 64)) h->kdense_ta = atoi(kta);
   const char* cd1 = getenv("MGP_CG_DENSE1");
   if (cd1) h->cg_dense1 = atoi(cd1);
+  const char* cpp = getenv("MGP_CG_PIPELINE_POLLS");
+  if (cpp) h->poll_pipeline = atoi(cpp) != 0;
   const char* tm = getenv("MGP_TRI_MIN_N");
   if (tm && atol(tm) > 0) h->tri_min_n = atol(tm);
   const char* ns = getenv("MGP_NOSPLIT_PER_CU");
@@ -131,6 +133,8 @@ extern "C" int mgp_destroy(mgp_handle* h) {
     if (h->prof_clk) (void)hipFree(h->prof_clk);
   }
   if (h->host_flag) (void)hipHostFree(h->host_flag);
+  for (auto& e : h->poll_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);
   if (h->e2tabs) (void)hipFree(h->e2tabs);

@@ -174,14 +174,17 @@ __global__ __launch_bounds__(NT) void cg_update_fused_kernel(CgCtrl* __restrict_
                                                              T thr, T min_float, const T* __restrict__ dinv,
                                                              int max_it, int ap_slices, long ap_stride,
                                                              const T* __restrict__ agree, int world) {
-  if (ctrl->active == 0) return;
   // multi-rank SGPR operator: `ap` is the all-reduced partial itself and `agree` the word behind it -- the sum of
   // the ranks' gate words.  Unless every rank computed this application nobody uses it: the gate closes and all
   // ranks leave the loop on the same iteration (what finish_allreduce_kernel did in a launch of its own).
+  // Tested BEFORE the gate word: in this branch workgroup 0 clears ctrl->active, and no workgroup of the launch may be
+  // reading that word at its entry meanwhile -- here none does, every one of them leaves on `agree`.  The
+  // other writer of ctrl->active, the last arriver below, runs after every workgroup has passed this point.
   if (agree != nullptr && *agree != (T)world) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->active = 0;
     return;
   }
+  if (ctrl->active == 0) return;
   __shared__ T red[2][NT / 64];
   __shared__ int last_flag;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -485,6 +488,8 @@ int check_operator(mgp_handle* h, const mgp_operator* op) {
   return MGP_OK;
 }
 
+constexpr int kRetryWithoutPersist = 1;  // internal: never crosses the C ABI
+
 template <typename T>
 int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, const T* B, const T* V0, long Bt,
                 double thr, long max_it, long cycle, double min_float, int check_every, T* V, T* err_out,
@@ -528,7 +533,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   const bool dense1 = op->kind == MGP_OP_DENSE && Bt == 1 && !dense_pre && pc.kind != MGP_PRE_BLOCK && cycle > max_it &&
                       mgp_dense1_eligible(h, n);
   size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64 +
-                 (dense1 ? mgp_dense1_bytes(op->dtype, n) : 0);
+                 (dense1 ? mgp_dense1_bytes(h, op->dtype, n) : 0);
   MGP_TRY(mgp_reserve(h, &h->cg, &h->cg_bytes, bytes));
   T* r = (T*)h->cg;
   T* p = r + tot;
@@ -568,10 +573,17 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
     MGP_HIP(h, hipMemsetAsync(V, 0, (size_t)tot * sizeof(T), s));
   }
   MgpDense1 d1;
+  // n <= 4096: the whole solve in one launch, the upper triangle of A in registers (cg_dense1.hip)
+  const bool persist = dense1 && !h->d1_persist_off && mgp_dense1_persist_eligible(h, n);
   if (dense1) {
     MGP_TRY(mgp_dense1_begin(h, &d1, op->dtype, op->A, n, B, av, V, r,
-                             pc.kind == MGP_PRE_JACOBI ? pc.diag_inv : nullptr, ctrl, d1_arena, thr, min_float, max_it));
+                             pc.kind == MGP_PRE_JACOBI ? pc.diag_inv : nullptr, ctrl, d1_arena, thr, min_float, max_it,
+                             persist ? 1 : 0));
     MGP_TRY(mgp_dense1_finish(h, &d1, rz, err_out, over));  // statistics of r_0 and the first gate
+    if (persist) {
+      MGP_TRY(mgp_dense1_persist_run(h, &d1));
+      MGP_TRY(mgp_dense1_finish(h, &d1, rz, err_out, over));  // final statistics; closes the gate
+    }
   } else if (!dense_pre) {
     hipLaunchKernelGGL((cg_init_kernel<T>), dim3((unsigned)Bt), dim3(256), 0, s, B, av, r, z, p, rz, over, err_out,
                        n, (T)thr, pc);
@@ -603,10 +615,51 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   if (check_every < 1) check_every = 1;
   long enq = 0;  // iterations enqueued so far (index of the next one)
   CgCtrl host{1, 0};
-  while (true) {
+  if (persist) {
     MGP_HIP(h, hipMemcpyAsync(h->host_flag, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, s));
     MGP_HIP(h, hipStreamSynchronize(s));
     memcpy(&host, h->host_flag, sizeof(CgCtrl));
+    // a hand-off ran out of its poll budget (a workgroup was not resident: the chip was shared): the caller retries
+    // this solve with the two-launch form
+    if (host.pad) return kRetryWithoutPersist;
+  } else if (dense1 && h->poll_pipeline) {
+    // One polled batch stays in flight: the device works on batch i + 1 while the host waits for the control word of
+    // batch i (round 3: every poll drained the stream, ~20 us each, 10 of them in a 248-step solve).  When a batch
+    // reports the end, the one behind it is already enqueued -- its launches are gated off on the device.
+    MGP_HIP(h, hipMemcpyAsync(h->host_flag, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, s));
+    MGP_HIP(h, hipStreamSynchronize(s));
+    memcpy(&host, h->host_flag, sizeof(CgCtrl));
+    for (int e = 0; e < 2; ++e)
+      if (!h->poll_ev[e]) MGP_HIP(h, hipEventCreateWithFlags(&h->poll_ev[e], hipEventDisableTiming));
+    CgCtrl* slots = (CgCtrl*)h->host_flag;  // 64 pinned bytes: two control words fit behind the first
+    int inflight = 0, wr = 0, rd = 0;
+    bool more = host.active != 0;
+    while (more || inflight > 0) {
+      while (more && inflight < 2 && enq < max_it) {
+        long batch = check_every;
+        if (enq + batch > max_it) batch = max_it - enq;
+        for (long q = 0; q < batch; ++q, ++enq) MGP_TRY(mgp_dense1_step(h, &d1, enq + 1));
+        MGP_TRY(mgp_dense1_finish(h, &d1, rz, err_out, over));
+        MGP_HIP(h, hipMemcpyAsync(&slots[1 + wr], ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, s));
+        MGP_HIP(h, hipEventRecord(h->poll_ev[wr], s));
+        wr ^= 1;
+        ++inflight;
+      }
+      if (inflight == 0) break;
+      MGP_HIP(h, hipEventSynchronize(h->poll_ev[rd]));
+      memcpy(&host, &slots[1 + rd], sizeof(CgCtrl));
+      rd ^= 1;
+      --inflight;
+      if (host.pad) return mgp_fail(h, MGP_E_HIP, "dense CG: a hand-off inside the iteration kernel timed out");
+      if (!host.active || enq >= max_it) more = false;
+      if (!host.active) break;  // what is still in flight does nothing (device gate); no need to wait for it
+    }
+  }
+  while (!persist && !(dense1 && h->poll_pipeline)) {
+    MGP_HIP(h, hipMemcpyAsync(h->host_flag, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, s));
+    MGP_HIP(h, hipStreamSynchronize(s));
+    memcpy(&host, h->host_flag, sizeof(CgCtrl));
+    if (dense1 && host.pad) return mgp_fail(h, MGP_E_HIP, "dense CG: a hand-off inside the iteration kernel timed out");
     if (!host.active || enq >= max_it) break;
     long batch = check_every;
     if (enq + batch > max_it) batch = max_it - enq;
@@ -731,11 +784,23 @@ extern "C" int mgp_pcg_solve(mgp_handle* h, const mgp_operator* op, const mgp_pr
   if (max_iterations < 0) return mgp_fail(h, MGP_E_BADARG, "max_iterations < 0");
   if (max_steps_cycle < 1) return mgp_fail(h, MGP_E_BADARG, "max_steps_cycle < 1");
   if (Bt > 2147483647L) return mgp_fail(h, MGP_E_SHAPE, "Bt too large");
-  if (op->dtype == MGP_F64)
-    return pcg_solve_t<double>(h, op, pre, (const double*)B, (const double*)V0, Bt, error_threshold, max_iterations,
-                               max_steps_cycle, min_float, check_every, (double*)V_out, (double*)err_out, stats);
-  return pcg_solve_t<float>(h, op, pre, (const float*)B, (const float*)V0, Bt, error_threshold, max_iterations,
-                            max_steps_cycle, min_float, check_every, (float*)V_out, (float*)err_out, stats);
+  auto run = [&]() -> int {
+    if (op->dtype == MGP_F64)
+      return pcg_solve_t<double>(h, op, pre, (const double*)B, (const double*)V0, Bt, error_threshold, max_iterations,
+                                 max_steps_cycle, min_float, check_every, (double*)V_out, (double*)err_out, stats);
+    return pcg_solve_t<float>(h, op, pre, (const float*)B, (const float*)V0, Bt, error_threshold, max_iterations,
+                              max_steps_cycle, min_float, check_every, (float*)V_out, (float*)err_out, stats);
+  };
+  int rc = run();
+  if (rc == kRetryWithoutPersist) {
+    if (V0 != nullptr && V0 == V_out)
+      return mgp_fail(h, MGP_E_HIP, "dense CG: a hand-off between resident workgroups timed out (is the GPU shared?) and "
+                                    "the initial solution was overwritten in place; set MGP_CG_DENSE1=1");
+    h->d1_persist_off = true;  // the solve again, from its inputs, two launches per iteration
+    rc = run();
+    h->d1_persist_off = false;
+  }
+  return rc;
 }
 
 extern "C" int mgp_operator_apply(mgp_handle* h, const mgp_operator* op, const void* P, int64_t Bt, void* out) {

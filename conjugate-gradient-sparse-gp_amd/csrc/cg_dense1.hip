@@ -61,7 +61,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void d1_init_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ b,
                                                      const T* __restrict__ av, T* __restrict__ r,
                                                      const T* __restrict__ dinv, T* __restrict__ cpart,
-                                                     T* __restrict__ scal, long n) {
+                                                     T* __restrict__ scal, T* __restrict__ zpub, long n) {
   const int l = threadIdx.x;
   const long i = (long)blockIdx.x * 64 + l;
   T rv = 0, zv = 0;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64) void d1_init_kernel(MgpCgCtrl* __restrict__ ctr
     rv = av ? b[i] - av[i] : b[i];
     r[i] = rv;
     zv = dinv ? rv * dinv[i] : rv;
+    zpub[i] = zv;  // z_0 for the register-resident form
   }
   const T prz = wave_allsum(zv * rv), prr = wave_allsum(rv * rv);
   if (l == 0) {
@@ -80,15 +81,16 @@ __global__ __launch_bounds__(64) void d1_init_kernel(MgpCgCtrl* __restrict__ ctr
       ctrl->active = 1;
       ctrl->iters = 0;
       ctrl->ticket = 0;
+      ctrl->pad = 0;
     }
   }
 }
 
 // statistics + gate for the host poll (once per enqueued batch)
 template <typename T>
-__global__ __launch_bounds__(64) void d1_finish_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ cpart,
-                                                       T* __restrict__ rz, T* __restrict__ err,
-                                                       int* __restrict__ over, T thr, int max_it) {
+__global__ __launch_bounds__(64) void d1_finish_kernel(MgpCgCtrl* __restrict__ ctrl, const int* __restrict__ hand_off_err,
+                                                       const T* __restrict__ cpart, T* __restrict__ rz,
+                                                       T* __restrict__ err, int* __restrict__ over, T thr, int max_it) {
   T s_rz, s_rr;
   sum_shares(cpart, (int)threadIdx.x, s_rz, s_rr);
   if (threadIdx.x == 0) {
@@ -96,18 +98,26 @@ __global__ __launch_bounds__(64) void d1_finish_kernel(MgpCgCtrl* __restrict__ c
     err[0] = (T)0.5 * s_rz;
     const int any = ((T)0.5 * s_rr > thr) ? 1 : 0;
     over[0] = any;
-    if (ctrl->active) ctrl->active = (any && ctrl->iters < max_it) ? 1 : 0;
+    if (*hand_off_err) ctrl->pad = 1;  // the register-resident form ran out of a poll budget
+    if (ctrl->active) ctrl->active = (any && ctrl->iters < max_it && !*hand_off_err) ? 1 : 0;
   }
 }
 
 template <typename T, bool JAC>
-__global__ __launch_bounds__(256) void d1_tile_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ A, long n,
+__global__ __launch_bounds__(256) void d1_tile_kernel(const MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ A, long n,
                                                       const T* __restrict__ r, const T* __restrict__ dinv,
                                                       const T* __restrict__ p_old, T* __restrict__ p_new,
                                                       const T* __restrict__ cpart, T* __restrict__ scal, int k,
                                                       const int2* __restrict__ tab, T* __restrict__ Q,
-                                                      T* __restrict__ tpart, T thr, T min_float, int max_it) {
-  if (ctrl->active == 0) return;
+                                                      T* __restrict__ tpart, T thr, T min_float, int max_it,
+                                                      int* __restrict__ stopw) {
+  // Gate: `active` is written by finish kernels only, stopw[(k-1) & 1] by the tile kernel of the PREVIOUS iteration --
+  // nothing this launch writes (block 0 used to clear ctrl->active while other workgroups of the same
+  // launch read it at entry).  A shut launch hands the shut on, so every later launch of the batch stays shut.
+  if (ctrl->active == 0 || stopw[(k + 1) & 1] != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) stopw[k & 1] = 1;
+    return;
+  }
   constexpr int TS = 64;
   __shared__ T colp[4][TS];
   __shared__ T wsum[4];
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void d1_tile_kernel(MgpCgCtrl* __restrict__ ct
   const bool live = (T)0.5 * rr_new > thr && it < max_it;
   if (b == 0 && t == 0) {
     if (live) scal[(k + 1) & 1] = rz_new;  // U_k's numerator of gamma, T_{k+1}'s rz_old
-    else ctrl->active = 0;
+    stopw[k & 1] = live ? 0 : 1;           // read by U_k and T_{k+1}, one launch later each
   }
   const bool drop = rz_old <= min_float;  // :79; also how the first direction p_1 = z_0 comes out
   const T beta = drop ? (T)0 : rz_new / rz_old;
@@ -199,8 +209,8 @@ __global__ __launch_bounds__(NT) void d1_update_kernel(MgpCgCtrl* __restrict__ c
                                                        const T* __restrict__ scal, int k, const T* __restrict__ p,
                                                        T* __restrict__ v, T* __restrict__ r,
                                                        const T* __restrict__ dinv, T* __restrict__ cpart, long n,
-                                                       T min_float) {
-  if (ctrl->active == 0) return;
+                                                       T min_float, const int* __restrict__ stopw) {
+  if (ctrl->active == 0 || stopw[k & 1] != 0) return;  // T_k (the previous launch) found the solve finished
   constexpr int NW = NT / 64;
   __shared__ T part[NW][64];
   __shared__ T red[NW];
@@ -260,9 +270,469 @@ __global__ __launch_bounds__(NT) void d1_update_kernel(MgpCgCtrl* __restrict__ c
   }
 }
 
+// write-through store / L1-bypassing load of one element (global_store/load ... sc1): the two halves of a hand-off
+// between resident workgroups without fences (MI355X_MICROARCH.md, hand-off table)
+// ---- cross-lane moves on the vector ALU (gfx950): `__shfl_xor` lowers to ds_bpermute -- the LDS crossbar, ~100
+// cycles of latency per dependent step -- which the tile kernels above hide behind seven workgroups per CU; the
+// register-resident kernel runs three waves per SIMD, so its reduction chains use DPP (within a row of 16 lanes) and
+// v_permlane16_swap / v_permlane32_swap (between rows / halves) instead.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// value of lane l ^ M for M = 1, 2, 4, 8 (inside a row of 16 lanes)
+template <int M, typename T>
+__device__ __forceinline__ T lane_xor_row(T v) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8, "row-local masks");
+  if (M == 1) return dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (M == 2) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (M == 8) return dpp_mov<0x128>(v);  // row_ror:8
+  return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror (l -> l ^ 7) then quad_perm [3,2,1,0] (l -> l ^ 3)
+}
+// (a', b') = swap: HALF32: a.hi <-> b.lo (lanes 32..63 of a with lanes 0..31 of b); else rows: a.row1 <-> b.row0, a.row3 <-> b.row2
+template <bool HALF32>
+__device__ __forceinline__ void lane_swap(double& a, double& b) {
+  int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  if (HALF32) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    alo = r0[0], blo = r0[1], ahi = r1[0], bhi = r1[1];
+  } else {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    alo = r0[0], blo = r0[1], ahi = r1[0], bhi = r1[1];
+  }
+  a = __hiloint2double(ahi, alo);
+  b = __hiloint2double(bhi, blo);
+}
+template <bool HALF32>
+__device__ __forceinline__ void lane_swap(float& a, float& b) {
+  int ai = __float_as_int(a), bi = __float_as_int(b);
+  if (HALF32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(ai, bi, false, false);
+    ai = r[0], bi = r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap(ai, bi, false, false);
+    ai = r[0], bi = r[1];
+  }
+  a = __int_as_float(ai);
+  b = __int_as_float(bi);
+}
+// reduce-scatter step across lane bit 32 (HALF32) or 16: lanes with the bit clear keep `lo` and receive the partner's
+// `lo`, lanes with it set keep `hi` and receive the partner's `hi` -- after the swap both are a' + b'
+template <bool HALF32, typename T>
+__device__ __forceinline__ T rs_swap_add(T lo, T hi) {
+  lane_swap<HALF32>(lo, hi);
+  return lo + hi;
+}
+// sum over the 64 lanes, the same bits in every lane (each step adds the two partners' values, a + b == b + a)
+template <typename T>
+__device__ __forceinline__ T wave_allsum_valu(T v) {
+  v = rs_swap_add<true>(v, v);
+  v = rs_swap_add<false>(v, v);
+  v += lane_xor_row<8>(v);
+  v += lane_xor_row<4>(v);
+  v += lane_xor_row<2>(v);
+  v += lane_xor_row<1>(v);
+  return v;
+}
+// reduce-scatter steps inside a row of 16 lanes (BIT = 8 or 4): x[k] <- keep + partner's send, HALF sums stay
+template <typename T, int HALF, int BIT>
+__device__ __forceinline__ void rs_step_row(T (&x)[16], int l) {
+  const bool hi = (l & BIT) != 0;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const T keep = hi ? x[k + HALF] : x[k];
+    const T send = hi ? x[k] : x[k + HALF];
+    x[k] = keep + lane_xor_row<BIT>(send);
+  }
+}
+
+// workgroup barrier that orders LDS only (no wait for vector-memory operations in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__device__ __forceinline__ T ld_sc1(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_sc1(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------ round 4: the matrix stays ON THE CHIP
+// For n <= 4096 the upper triangle of A (67 MB of 64 x 64 tiles at n = 4096) fits the register files of the chip
+// (256 CUs x 512 KB): one launch loads every tile ONCE -- a workgroup of 768 threads per CU (twelve waves, three per
+// SIMD) holds up to nine tiles, three per four-wave group: two in registers, 16 elements per lane and tile, one in
+// LDS -- and then runs
+// the WHOLE solve, conjugate_gradient.py:59-98, without touching A again.  What is left of an iteration is its two
+// global reductions, as hand-offs between resident workgroups in the form of cdna_hip_programming.md Guideline 16, R2 --
+// THE DATA IS THE FLAG: every published number travels as 8-byte granules {epoch, 32 bits of the value}, each written
+// by ONE write-through (sc1) 8-byte store and re-read with sc1 loads until its tag is the epoch the reader waits for.
+// No flag word, no fence, no atomic, no drain-then-signal: a consumer's poll IS its data load, so a phase costs one
+// memory round trip after the last producer's store has landed (the flag form measured 13.3 us per iteration at
+// n = 4096: four dependent round trips of ~1.5 us each).
+//   A_k  every workgroup -> the chunk owners: the tiles' slots Q and one share of p.Ap per workgroup, epoch k + 1
+//   B_k  the chunk owners -> every workgroup: z = M^-1 r of the chunk and its shares of rz, ||r||^2, epoch k + 2
+//        (epoch 1 = the initial residual, written by d1_init_kernel)
+// Every wave forms the stopping rule (:59-62) and beta from the same 2 nt shares, so all workgroups leave the loop on
+// the same iteration with no further word exchanged.  A buffer is rewritten only after every reader has published
+// something that depends on having read it (slots and shares of p.Ap: read before an owner publishes B; z and the
+// chunk shares: read before a workgroup publishes A), so single buffers suffice and a reader never meets a later
+// epoch.  Every wait is bounded (a poll budget, then the error word and out): a workgroup that is not resident --
+// another stream holding CUs -- makes the solve fail over to the two-launch form, never hang.
+using gu64 = unsigned long long;
+constexpr int kPersistBudget = 1 << 16;  // polls of >= 1 us each
+
+template <typename T>
+struct Gran;  // element <-> granules
+template <>
+struct Gran<double> {
+  static constexpr int W = 2;  // granules per element
+  static __device__ __forceinline__ void store(gu64* g, unsigned epoch, double v) {
+    const gu64 tag = (gu64)epoch << 32;
+    __hip_atomic_store(g, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ bool load(const gu64* g, unsigned epoch, double& v) {
+    const gu64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const gu64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+    return (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
+  }
+};
+template <>
+struct Gran<float> {
+  static constexpr int W = 1;
+  static __device__ __forceinline__ void store(gu64* g, unsigned epoch, float v) {
+    __hip_atomic_store(g, ((gu64)epoch << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ bool load(const gu64* g, unsigned epoch, float& v) {
+    const gu64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __int_as_float((int)(unsigned)a);
+    return (unsigned)(a >> 32) == epoch;
+  }
+};
+
+// granule arrays of one solve (zeroed by mgp_dense1_begin: a tag left by an earlier solve must never match)
+struct D1PBuf {
+  gu64* Qg;    // [nt][n] elements: slot k of output element i
+  gu64* wpg;   // [256] elements: the workgroups' shares of p.Ap
+  gu64* cg;    // [2][64] elements: the chunks' shares of rz and of ||r||^2
+  gu64* zg;    // [n] elements: z = M^-1 r
+  int* err;
+};
+
+// epoch-1 granules of the initial residual (d1_init_kernel left z_0 in zpub and the shares in cpart)
+template <typename T>
+__global__ __launch_bounds__(64) void d1_persist_seed_kernel(const T* __restrict__ zpub, const T* __restrict__ cpart,
+                                                             D1PBuf pb, long n, int nt) {
+  constexpr int W = Gran<T>::W;
+  const int l = threadIdx.x;
+  const long i = (long)blockIdx.x * 64 + l;
+  if (i < n) Gran<T>::store(pb.zg + i * W, 1u, zpub[i]);
+  if (blockIdx.x == 0 && l < nt) {
+    Gran<T>::store(pb.cg + (long)l * W, 1u, cpart[l]);
+    Gran<T>::store(pb.cg + (long)(64 + l) * W, 1u, cpart[CP + l]);
+  }
+}
+
+template <typename T, bool JAC>
+__global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
+                                                         const T* __restrict__ A, long n, int nt, long ntiles,
+                                                         T* __restrict__ r, T* __restrict__ v,
+                                                         const T* __restrict__ dinv, T* __restrict__ cpart,
+                                                         const int2* __restrict__ tab, T thr, T min_float, int max_it,
+                                                         unsigned long long* __restrict__ trace) {
+  constexpr int TS = 64;
+  constexpr int W = Gran<T>::W;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..11: twelve waves, three per SIMD, up to 168 VGPRs each
+  // diagnosis (MGP_D1_TRACE=<file>): thread 0 of workgroups 0 (owner of chunk 0) and 1 (no chunk) stamps the 100 MHz
+  // constant counter at points of the first 64 iterations: trace[wg][iteration][point]
+  auto stamp = [&](int it, int point) {
+    if (trace != nullptr && t == 0 && blockIdx.x < 2 && it < 64)
+      trace[((long)blockIdx.x * 64 + it) * 8 + point] = wall_clock64();
+  };
+  const int g = w >> 2, wq = w & 3;                       // four-wave group (0..2), wave in the group
+  const int G = (int)gridDim.x, me = (int)blockIdx.x;
+  __shared__ T pJ[9][TS], pI[9][TS], pOwn[TS];
+  __shared__ T colp[3][3][4][TS];   // [layer][group][wave][column]
+  __shared__ T gsum[3][3][4];       // [layer][group][wave]: share of p.Ap
+  __shared__ T part[12][TS];        // owner: slot sums per wave
+  __shared__ T rOwn[TS], vOwn[TS], dOwn[TS], shOwn[2];  // owner: its chunk of r, v, 1/diag and its latest shares (LDS, not
+                                                       // registers: loop-carried values of one wave spill in all twelve)
+  __shared__ T sh_s[3];  // rz, ||r||^2 of the current residual (from wave 0), p.Ap (from the owner's polling wave)
+  __shared__ int fail_s;
+  // third tile of each four-wave group: 3 x 64 x 64 elements of dynamic LDS (96 KB in fp64) -- three REGISTER layers
+  // (96 VGPRs in fp64) left ~70 for everything else and the loop spilled; a reload in the owner's update forces
+  // `s_waitcnt vmcnt(0)`, i.e. a wait for this wave's write-through stores: 2.8 us per iteration in the timeline
+  extern __shared__ __attribute__((aligned(16))) unsigned char d1p_dyn_lds[];
+  T(*a2s)[TS] = reinterpret_cast<T(*)[TS]>(d1p_dyn_lds) + (long)g * TS;  // rows of this group's tile
+  if (t == 0) fail_s = 0;
+  // ---- tiles of this workgroup: slot s = b / G for b = me + s G; slot s belongs to group s % 3, layer s / 3
+  const long nmine = ntiles > me ? (ntiles - me + G - 1) / G : 0;  // <= 9
+  int tI[3], tJ[3];
+#pragma unroll
+  for (int ly = 0; ly < 3; ++ly) {
+    const long s = (long)ly * 3 + g;
+    const bool have = s < nmine;
+    const int2 ij = tab[have ? me + s * G : 0];
+    tI[ly] = have ? ij.x : -1;
+    tJ[ly] = have ? ij.y : -1;
+  }
+  // ---- load the tiles ONCE (rows 16 wq .. 16 wq + 15 of the tile, lane = column; ragged edges are zeros)
+  T a0[16], a1[16];
+#pragma unroll
+  for (int ly = 0; ly < 3; ++ly) {
+    const bool have = tI[ly] >= 0;
+    const long r0 = (long)(have ? tI[ly] : 0) * TS + 16 * wq, c = (long)(have ? tJ[ly] : 0) * TS + l;
+    const long cj = c < n ? c : n - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long row = r0 + q < n ? r0 + q : n - 1;
+      T x = A[row * n + cj];
+      x = (have && r0 + q < n && c < n) ? x : (T)0;
+      if (ly == 0) a0[q] = x;
+      else if (ly == 1) a1[q] = x;
+      else a2s[16 * wq + q][l] = x;
+    }
+  }
+  // ---- chunk ownership: chunk c belongs to workgroup (37 c) mod G -- spread over the XCDs; G >= nt
+  int own = -1;
+  for (int c = 0; c < nt; ++c)
+    if ((int)(((long)c * 37) % G) == me) own = c;
+  const long oi = (long)(own >= 0 ? own : 0) * TS + l;
+  const bool ook = own >= 0 && oi < n;
+  if (w == 0 && own >= 0) {  // the owner's chunk of r and v stays on the chip for the whole solve
+    rOwn[l] = ook ? r[oi] : (T)0;
+    vOwn[l] = ook ? v[oi] : (T)0;
+    dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
+    if (l == 0) {
+      shOwn[0] = cpart[own];
+      shOwn[1] = cpart[CP + own];
+    }
+  }
+  T rz_old = 0;  // rz of the previous iteration: 0 makes p_1 = z_0 (the beta-term dropped, :79-84)
+  int k = 0;     // completed iterations
+  __syncthreads();
+  while (true) {
+    // An opaque zero added to every index formed below: without it the compiler hoists some thirty loop-invariant
+    // 64-bit addresses out of the loop and spills them (the three register layers of the matrix leave ~70 VGPRs)
+    long kz = 0;
+    asm volatile("" : "+s"(kz));
+    stamp(k, 0);
+    // ================================================================= B_k: shares and z of the residual after k steps
+    // Who polls matters: 3072 waves re-reading all shares every round trip were ~10 TB/s of write-through-line reads
+    // and the owners' own loads and stores queued behind them (15.5 us per iteration).  ONE wave per workgroup polls the
+    // 2 nt shares; the waves with a duty poll only their own z chunk -- wave (g, wq) per layer: wq == 0 -> p_J of the
+    // group's tile, wq == 1 -> p_I; wave 11: the owner's chunk -- and everybody else waits at the workgroup barrier.
+    const unsigned eb = (unsigned)k + 1u;
+    T zj[3] = {0, 0, 0}, zo = 0;
+    {
+      const bool duty = (wq < 2 && tI[0] >= 0) || (w == 11 && own >= 0) || w == 0;
+      T z0 = 0, q0 = 0;
+      bool ok = !duty;
+      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+        bool mine = true;
+        if (w == 0 && l < nt) {
+          mine = Gran<T>::load(pb.cg + (long)(l + kz) * W, eb, z0) && mine;
+          mine = Gran<T>::load(pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
+        }
+#pragma unroll
+        for (int ly = 0; ly < 3; ++ly) {
+          if (tI[ly] >= 0 && wq < 2) {
+            const long e = (long)(wq == 0 ? tJ[ly] : tI[ly]) * TS + l + kz;
+            if (e < n) mine = Gran<T>::load(pb.zg + e * W, eb, zj[ly]) && mine;
+          }
+        }
+        if (w == 11 && ook) mine = Gran<T>::load(pb.zg + (oi + kz) * W, eb, zo) && mine;
+        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok && l == 0) fail_s = 1;
+      if (w == 0) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
+        const T a_rz = wave_allsum_valu(z0), a_rr = wave_allsum_valu(q0);
+        if (l == 0) {
+          sh_s[0] = a_rz;
+          sh_s[1] = a_rr;
+        }
+      }
+    }
+    __syncthreads();
+    stamp(k, 1);
+    if (fail_s) break;
+    const T rz_new = sh_s[0], rr_new = sh_s[1];
+    const bool live = (T)0.5 * rr_new > thr && k < max_it;  // :59-62
+    if (!live) break;
+    const bool drop = rz_old <= min_float;  // :79
+    const T beta = drop ? (T)0 : rz_new / rz_old;
+#pragma unroll
+    for (int ly = 0; ly < 3; ++ly) {
+      if (tI[ly] >= 0 && wq < 2) {
+        const int s = ly * 3 + g;
+        T* dst = wq == 0 ? pJ[s] : pI[s];
+        dst[l] = drop ? zj[ly] : mgp_fma(beta, dst[l], zj[ly]);  // a select, not 0 * p: LDS holds anything at start-up
+      }
+    }
+    if (w == 11 && own >= 0) pOwn[l] = drop ? zo : mgp_fma(beta, pOwn[l], zo);
+    rz_old = rz_new;
+    lds_barrier();
+    stamp(k, 2);
+    // ================================================================= tile products of iteration k + 1, epoch k + 1
+    const unsigned ea = (unsigned)k + 1u;
+#pragma unroll
+    for (int ly = 0; ly < 3; ++ly) {
+      if (tI[ly] >= 0) {  // uniform per group
+        const int s = ly * 3 + g;
+        const int I = tI[ly], J = tJ[ly];
+        const T pj = pJ[s][l];
+        // the first reduce-scatter step (rows q and q + 8 meet across lane bit 32) is taken as the products are formed:
+        // eight sums live instead of sixteen next to the three register layers of the matrix
+        T x[16];
+        T cs = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const T alo = ly == 0 ? a0[q] : (ly == 1 ? a1[q] : a2s[16 * wq + q][l]);
+          const T ahi = ly == 0 ? a0[q + 8] : (ly == 1 ? a1[q + 8] : a2s[16 * wq + q + 8][l]);
+          cs = mgp_fma(alo, pI[s][16 * wq + q], cs);  // the same address in every lane: an LDS broadcast read
+          x[q] = rs_swap_add<true>(alo * pj, ahi * pj);  // rows q and q + 8 meet across lane bit 32
+        }
+#pragma unroll
+        for (int q = 8; q < 16; ++q) {
+          const T aq = ly == 0 ? a0[q] : (ly == 1 ? a1[q] : a2s[16 * wq + q][l]);
+          cs = mgp_fma(aq, pI[s][16 * wq + q], cs);
+        }
+        colp[ly][g][wq][l] = cs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = rs_swap_add<false>(x[q], x[q + 4]);  // lane bit 16
+        rs_step_row<T, 2, 8>(x, l);
+        rs_step_row<T, 1, 4>(x, l);
+        T sr = x[0];
+        sr += lane_xor_row<2>(sr);
+        sr += lane_xor_row<1>(sr);  // lane l: (A_IJ p_J)[16 wq + (l >> 2)]
+        const long i = (long)I * TS + 16 * wq + (l >> 2) + kz;
+        if ((l & 3) == 0 && i < n) Gran<T>::store(pb.Qg + ((long)J * n + i) * W, ea, sr);
+        const T prow = pI[s][16 * wq + (l >> 2)];
+        const T u = wave_allsum_valu((l & 3) == 0 ? sr * prow : (T)0);
+        if (l == 0) gsum[ly][g][wq] = u;
+      }
+    }
+    lds_barrier();
+    T share = 0;
+#pragma unroll
+    for (int ly = 0; ly < 3; ++ly) {
+      if (tI[ly] >= 0) {
+        const int I = tI[ly], J = tJ[ly];
+        if (wq == ly && I != J) {  // the column sums of layer ly by wave ly of the group: three waves share the three layers
+          const T sc = (colp[ly][g][0][l] + colp[ly][g][1][l]) + (colp[ly][g][2][l] + colp[ly][g][3][l]);
+          const long ic2 = (long)J * TS + l + kz;
+          if (ic2 < n) Gran<T>::store(pb.Qg + ((long)I * n + ic2) * W, ea, sc);
+        }
+        const T tot = (gsum[ly][g][0] + gsum[ly][g][1]) + (gsum[ly][g][2] + gsum[ly][g][3]);
+        share += I == J ? tot : tot + tot;  // the same in the four waves of the group
+      }
+    }
+    lds_barrier();
+    // the workgroup's share of p.Ap: per group its layers in order, then the groups in order
+    if (wq == 0 && l == 0) gsum[0][g][0] = share;
+    lds_barrier();
+    if (t == 0) Gran<T>::store(pb.wpg + (long)(me + kz) * W, ea, (gsum[0][0][0] + gsum[0][1][0]) + gsum[0][2][0]);
+    stamp(k, 3);
+    // ================================================================= the owner's update of iteration k + 1
+    if (own >= 0) {
+      // ONE wave polls the workgroups' shares of p.Ap (4 KB a round); a workgroup stores its share after its slots, so
+      // when all 256 carry the epoch the slots are (all but surely) there: the other waves wait at the barrier and
+      // then read the chunk's slots once -- every granule still checked, a stale one re-read
+      if (w == 11) {
+        T tp[4] = {0, 0, 0, 0};
+        bool ok = false;
+        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+          bool mine = true;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (m * 64 + l < G) mine = Gran<T>::load(pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
+          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && l == 0) fail_s = 1;
+        T d = 0;  // lane-sequential, then the butterfly
+#pragma unroll
+        for (int m = 0; m < 4; ++m) d += tp[m];
+        d = wave_allsum_valu(d);
+        if (l == 0) sh_s[2] = d;
+      }
+      __syncthreads();
+      stamp(k, 4);
+      // slots of the chunk: wave w adds slots 6 w .. 6 w + 5 (index order), then the waves in order
+      T sl[6] = {0, 0, 0, 0, 0, 0};
+      if (6 * w < nt) {
+        bool ok = false;
+        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+          bool mine = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            if (6 * w + q < nt && oi < n)
+              mine = Gran<T>::load(pb.Qg + ((long)(6 * w + q) * n + oi + kz) * W, ea, sl[q]) && mine;
+          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && l == 0) fail_s = 1;
+      }
+      stamp(k, 5);
+      T sacc = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) sacc += sl[q];
+      part[w][l] = sacc;
+      __syncthreads();
+      if (fail_s) break;
+      stamp(k, 6);
+      if (w == 0) {
+        const T d = sh_s[2];
+        const T gamma = (d <= min_float) ? (T)0 : rz_new / d;  // :66-68 (rz of the residual the direction was built from)
+        T ap = part[0][l];
+#pragma unroll
+        for (int q = 1; q < 12; ++q) ap += part[q][l];
+        const T rc = mgp_fma(-gamma, ap, rOwn[l]);  // :76
+        const T zn = JAC ? rc * dOwn[l] : rc;       // :77
+        if (ook) Gran<T>::store(pb.zg + (oi + kz) * W, ea + 1u, zn);  // first: the critical path of everybody else
+        const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
+        if (l == 0) {
+          Gran<T>::store(pb.cg + (long)(own + kz) * W, ea + 1u, prz);
+          Gran<T>::store(pb.cg + (long)(64 + own + kz) * W, ea + 1u, prr);
+          shOwn[0] = prz;
+          shOwn[1] = prr;
+        }
+        rOwn[l] = rc;
+        vOwn[l] = mgp_fma(gamma, pOwn[l], vOwn[l]);  // :69
+      }
+      stamp(k, 7);
+    }
+    ++k;
+  }
+  // ---- out: the owners write their chunk of the solution and the residual and their shares; workgroup 0 the counters
+  if (w == 0 && ook) {
+    v[oi] = vOwn[l];
+    r[oi] = rOwn[l];
+  }
+  if (w == 0 && own >= 0 && l == 0) {
+    cpart[own] = shOwn[0];
+    cpart[CP + own] = shOwn[1];
+  }
+  if (fail_s && t == 0) *pb.err = 1;
+  if (me == 0 && t == 0) ctrl->iters = k;
+}
+
 template <typename T>
 int d1_layout(MgpDense1* st, void* arena, long n) {
-  // arena: tpart[ntiles] | cpart[2 CP] | scal[2] | pb[2][n]
+  // arena: tpart[ntiles] | cpart[2 CP] | scal[2] | pb[2][n] | zpub[n] | hand-off error word (128-byte line of its own)
+  //        | granules of the register-resident form: Qg[nt n] | wpg[256] | cg[128] | zg[n]  (x W 8-byte words each)
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
   T* a = (T*)arena;
   st->tpart = a;
@@ -270,23 +740,40 @@ int d1_layout(MgpDense1* st, void* arena, long n) {
   st->scal = a + ntiles + 2 * CP;
   st->pb[0] = a + ntiles + 2 * CP + 2;
   st->pb[1] = a + ntiles + 2 * CP + 2 + n;
+  st->zpub = a + ntiles + 2 * CP + 2 + 2 * n;
+  st->sync = (void*)(((uintptr_t)(a + ntiles + 2 * CP + 2 + 3 * n) + 127) & ~(uintptr_t)127);
+  st->gran = (char*)st->sync + 128;
   return MGP_OK;
+}
+
+static size_t d1_gran_bytes(int dtype, long n) {
+  const long nt = (n + 63) / 64;
+  return (size_t)(nt * n + 256 + 128 + n) * (dtype == MGP_F64 ? 2 : 1) * sizeof(gu64);
 }
 
 }  // namespace
 
-size_t mgp_dense1_bytes(int dtype, int64_t n) {
+size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n) {
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
-  return (size_t)(ntiles + 2 * CP + 2 + 2 * n) * mgp_elem(dtype) + 64;
+  return (size_t)(ntiles + 2 * CP + 2 + 3 * n) * mgp_elem(dtype) + 128 + 128 +
+         (mgp_dense1_persist_eligible(h, n) ? d1_gran_bytes(dtype, n) : 0) + 64;
 }
 
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n) {
   return h->cg_dense1 != 0 && n >= h->tri_min_n && n <= 64L * CP;
 }
 
+// the register-resident form: every tile on the chip at once -- at most nine per workgroup, one workgroup per CU
+static int d1_persist_grid(const mgp_handle* h) { return h->num_cus < 256 ? h->num_cus : 256; }
+bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n) {
+  const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
+  const int G = d1_persist_grid(h);
+  return h->cg_dense1 >= 3 && mgp_dense1_eligible(h, n) && nt <= 64 && nt <= G && ntiles <= 9L * G;
+}
+
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
-                     int64_t max_it) {
+                     int64_t max_it, int persist) {
   st->dtype = dtype;
   st->A = A;
   st->n = n;
@@ -299,18 +786,92 @@ int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int
   st->max_it = (int)(max_it > 2147483647L ? 2147483647L : max_it);
   st->nt = (int)((n + 63) / 64);
   st->ntiles = (long)st->nt * (st->nt + 1) / 2;
+  st->persist = persist;
   if (dtype == MGP_F64) d1_layout<double>(st, arena, n);
   else d1_layout<float>(st, arena, n);
   MGP_HIP(h, hipMemsetAsync(st->cpart, 0, 2 * CP * mgp_elem(dtype), h->stream));  // shares of chunks beyond nt stay 0
+  // the hand-off error word and -- a tag left by an earlier solve must never match an epoch of this one -- every granule
+  MGP_HIP(h, hipMemsetAsync(st->sync, 0, 128 + (persist ? d1_gran_bytes(dtype, n) : 0), h->stream));
   // the product's slots and the tile table (dense.hip owns both)
   MGP_TRY(mgp_symm_gemv_tri_prepare(h, dtype, n, &st->Q, &st->tab));
   if (dtype == MGP_F64)
     hipLaunchKernelGGL((d1_init_kernel<double>), dim3((unsigned)st->nt), dim3(64), 0, h->stream, ctrl, (const double*)B,
-                       (const double*)av, (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal, (long)n);
+                       (const double*)av, (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal,
+                       (double*)st->zpub, (long)n);
   else
     hipLaunchKernelGGL((d1_init_kernel<float>), dim3((unsigned)st->nt), dim3(64), 0, h->stream, ctrl, (const float*)B,
-                       (const float*)av, (float*)r, (const float*)dinv, (float*)st->cpart, (float*)st->scal, (long)n);
+                       (const float*)av, (float*)r, (const float*)dinv, (float*)st->cpart, (float*)st->scal,
+                       (float*)st->zpub, (long)n);
   MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+template <typename T>
+static D1PBuf d1_pbuf(const MgpDense1* st) {
+  constexpr long W = Gran<T>::W;
+  D1PBuf pb;
+  pb.Qg = (gu64*)st->gran;
+  pb.wpg = pb.Qg + (long)st->nt * st->n * W;
+  pb.cg = pb.wpg + 256 * W;
+  pb.zg = pb.cg + 128 * W;
+  pb.err = (int*)st->sync;
+  return pb;
+}
+
+// the whole solve in one launch (after begin + finish have left the statistics of r_0 and the first gate)
+int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
+  const dim3 grid((unsigned)d1_persist_grid(h));
+  if (st->dtype == MGP_F64)
+    hipLaunchKernelGGL((d1_persist_seed_kernel<double>), dim3((unsigned)st->nt), dim3(64), 0, h->stream,
+                       (const double*)st->zpub, (const double*)st->cpart, d1_pbuf<double>(st), (long)st->n, st->nt);
+  else
+    hipLaunchKernelGGL((d1_persist_seed_kernel<float>), dim3((unsigned)st->nt), dim3(64), 0, h->stream,
+                       (const float*)st->zpub, (const float*)st->cpart, d1_pbuf<float>(st), (long)st->n, st->nt);
+  MGP_LAUNCH_CHECK(h);
+  unsigned long long* trace = nullptr;
+  const char* trace_path = getenv("MGP_D1_TRACE");
+  constexpr size_t kTraceWords = 2 * 64 * 8;
+  if (trace_path && *trace_path) {
+    MGP_HIP(h, hipMalloc((void**)&trace, kTraceWords * sizeof(unsigned long long)));
+    MGP_HIP(h, hipMemsetAsync(trace, 0, kTraceWords * sizeof(unsigned long long), h->stream));
+  }
+#define MGP_D1P(TT, JV)                                                                                             \
+  do {                                                                                                              \
+  MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_kernel<TT, JV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)(3 * 64 * 64 * sizeof(TT))));                                                  \
+  hipLaunchKernelGGL((d1_persist_kernel<TT, JV>), grid, dim3(768), 3 * 64 * 64 * sizeof(TT), h->stream, st->ctrl,     \
+                     d1_pbuf<TT>(st),                                                                                \
+                     (const TT*)st->A, (long)st->n, st->nt, st->ntiles, (TT*)st->r, (TT*)st->V, (const TT*)st->dinv,   \
+                     (TT*)st->cpart, (const int2*)st->tab, (TT)st->thr, (TT)st->min_float, st->max_it, trace);        \
+  } while (0)
+  if (st->dtype == MGP_F64) {
+    if (st->dinv) MGP_D1P(double, true);
+    else MGP_D1P(double, false);
+  } else {
+    if (st->dinv) MGP_D1P(float, true);
+    else MGP_D1P(float, false);
+  }
+#undef MGP_D1P
+  MGP_LAUNCH_CHECK(h);
+  if (trace) {  // diagnosis only: drains the stream
+    std::vector<unsigned long long> host(kTraceWords);
+    MGP_HIP(h, hipMemcpyAsync(host.data(), trace, kTraceWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    MGP_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(trace);
+    if (FILE* f = fopen(trace_path, "a")) {
+      fprintf(f, "# n=%ld: 100 MHz ticks relative to the workgroup's first stamp; columns: top, B read, p formed, tiles "
+                 "done and published, -, A read (owner), slots summed (owner), B published (owner)\n", (long)st->n);
+      for (int wg = 0; wg < 2; ++wg)
+        for (int it = 0; it < 64; ++it) {
+          const unsigned long long* e = &host[((size_t)wg * 64 + it) * 8];
+          if (!e[0]) continue;
+          fprintf(f, "wg %d it %2d:", wg, it);
+          for (int q = 0; q < 8; ++q) fprintf(f, " %7lld", e[q] ? (long long)(e[q] - host[(size_t)wg * 64 * 8]) : -1LL);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    }
+  }
   return MGP_OK;
 }
 
@@ -322,13 +883,13 @@ static int d1_step_t(mgp_handle* h, const MgpDense1* st, long k) {
   hipLaunchKernelGGL((d1_tile_kernel<T, JAC>), dim3((unsigned)st->ntiles), dim3(256), 0, h->stream, st->ctrl,
                      (const T*)st->A, (long)st->n, (const T*)st->r, (const T*)st->dinv, p_old, p_new,
                      (const T*)st->cpart, (T*)st->scal, kk, (const int2*)st->tab, (T*)st->Q, (T*)st->tpart, (T)st->thr,
-                     (T)st->min_float, st->max_it);
+                     (T)st->min_float, st->max_it, (int*)st->sync + 1);
   MGP_LAUNCH_CHECK(h);
 #define MGP_D1U(NTV, PERV, TPMV)                                                                                     \
   hipLaunchKernelGGL((d1_update_kernel<T, JAC, NTV, PERV, TPMV>), dim3((unsigned)st->nt), dim3(NTV), 0, h->stream,     \
                      st->ctrl, (const T*)st->Q, st->nt, (const T*)st->tpart, st->ntiles, (const T*)st->scal, kk,      \
                      (const T*)p_new, (T*)st->V, (T*)st->r, (const T*)st->dinv, (T*)st->cpart, (long)st->n,           \
-                     (T)st->min_float)
+                     (T)st->min_float, (const int*)st->sync + 1)
   if (st->nt <= 32) MGP_D1U(256, 8, 3);         // 528 tiles
   else if (st->nt <= 64) MGP_D1U(256, 16, 9);   // 2080 tiles
   else MGP_D1U(512, 16, 17);                    // nt <= 128: 8256 tiles
@@ -345,13 +906,15 @@ int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k) {
 }
 
 // statistics (rz, err, over) and the gate word for the host poll
-int mgp_dense1_finish(mgp_handle* h, const MgpDense1* st, void* rz, void* err, int* over) {
+int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* over) {
   if (st->dtype == MGP_F64)
-    hipLaunchKernelGGL((d1_finish_kernel<double>), dim3(1), dim3(64), 0, h->stream, st->ctrl, (const double*)st->cpart,
-                       (double*)rz, (double*)err, over, (double)st->thr, st->max_it);
+    hipLaunchKernelGGL((d1_finish_kernel<double>), dim3(1), dim3(64), 0, h->stream, st->ctrl,
+                       (const int*)st->sync, (const double*)st->cpart, (double*)rz, (double*)err,
+                       over, (double)st->thr, st->max_it);
   else
-    hipLaunchKernelGGL((d1_finish_kernel<float>), dim3(1), dim3(64), 0, h->stream, st->ctrl, (const float*)st->cpart,
-                       (float*)rz, (float*)err, over, (float)st->thr, st->max_it);
+    hipLaunchKernelGGL((d1_finish_kernel<float>), dim3(1), dim3(64), 0, h->stream, st->ctrl,
+                       (const int*)st->sync, (const float*)st->cpart, (float*)rz, (float*)err,
+                       over, (float)st->thr, st->max_it);
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;
 }

@@ -47,6 +47,9 @@ struct mgp_handle {
   size_t pool_bytes = 0, pool_used = 0;
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
+  hipEvent_t poll_ev[2] = {nullptr, nullptr};  // one polled batch of the dense one-RHS CG in flight (cg.hip)
+  bool d1_persist_off = false;  // set for the retry of a solve whose register-resident launch reported a timed-out hand-off
+  int poll_pipeline = 1;  // MGP_CG_PIPELINE_POLLS=0: drain the stream at every poll (round 3)
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
   void* e2tabs = nullptr;  // exp2 tables of the fast fp64 sweep (8192 + 2048 entries, sweep.hip: mgp_build_e2tabs)
   double* dparams = nullptr;  // device copy of c/lengthscale_d for the generic-D kernels [MGP_MAX_D]
@@ -81,10 +84,11 @@ struct mgp_handle {
   void* tri_tab = nullptr;  // (I, J) of the upper-triangle tiles in launch order, for tri_tab_nt tile rows
   size_t tri_tab_bytes = 0;
   int tri_tab_nt = 0;
-  // one-right-hand-side dense CG (the reference's literal loop, conjugate_gradient.py:65-84): 1 = two launches per
-  // iteration with no hand-off inside either (cg_dense1.hip), 0 = product (tile kernel + slot reduce) + fused
-  // update launch (MGP_CG_DENSE1)
-  int cg_dense1 = 1;
+  // one-right-hand-side dense CG (the reference's literal loop, conjugate_gradient.py:65-84): 3 = for n <= 4096 the
+  // whole solve in ONE launch with the upper triangle of A held in registers (cg_dense1.hip, round 4) and the
+  // two-launch iteration above that, 1 = two launches per iteration everywhere, 0 = product (tile kernel + slot
+  // reduce) + fused update launch (MGP_CG_DENSE1)
+  int cg_dense1 = 3;
   int kdense_ta = 0;  // rows of A per block of k_dense_kernel: 0 = by shape (16, or 64 at D > 8), else 16 or 64 (MGP_KDENSE_TA)
   int gemm_ksplit = 1;  // mid-size GEMMs: 128x128 tiles x K slices instead of 64x64 tiles (MGP_GEMM_KSPLIT=0 disables)
   int skinny_blocks_per_cu = 0;  // k slices of the skinny product: workgroups per CU to aim for; 0 = by panel width (MGP_SKINNY_BPC)
@@ -254,17 +258,22 @@ struct MgpDense1 {
   const void* dinv = nullptr;
   void *V = nullptr, *r = nullptr, *Q = nullptr, *tpart = nullptr, *cpart = nullptr, *scal = nullptr;
   void* pb[2] = {nullptr, nullptr};
+  // register-resident form (cg_dense1.hip, round 4): published z, the workgroups' shares of p.Ap, the hand-off flags
+  int persist = 0;
+  void *zpub = nullptr, *sync = nullptr, *gran = nullptr;
   const void* tab = nullptr;
   MgpCgCtrl* ctrl = nullptr;
   double thr = 0, min_float = 0;
 };
-size_t mgp_dense1_bytes(int dtype, int64_t n);
+size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n);
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n);
+bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n);
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
-                     int64_t max_it);
+                     int64_t max_it, int persist);
+int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st);
 int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k);
-int mgp_dense1_finish(mgp_handle* h, const MgpDense1* st, void* rz, void* err, int* over);
+int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* over);
 
 inline size_t mgp_elem(int dtype) { return dtype == MGP_F64 ? 8 : 4; }
 
