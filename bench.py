@@ -411,15 +411,48 @@ def main():
             (kl, t_kl) = timed(lambda: mdl.prior_kl(probes=probes))
             (_, t_ldg) = timed(lambda: mdl.logdet_gradient(1.0, probes=probes))
             it_us = 1e3 * t_cg / max(int(csteps), 1)
+            # C3's 64-probe solve on its own (the CG inside prior_kl / logdet_gradient): per iteration, against both of
+            # its rooflines -- 2 * 64 * M^2 flops on the fp64 matrix cores, M^2 elements of A streamed once
+            cgm.solve_with_stats(KL, probes)
+            ((_, (psteps, _)), t_pcg) = timed(lambda: cgm.solve_with_stats(KL, probes))
+            p_us = 1e3 * t_pcg / max(int(psteps), 1)
+            p_flops, p_bytes = 2.0 * 64 * M * M, float(esize) * M * M
+            # the same one-RHS solve at C2's size (M = 2048)
+            M2 = min(M, 2048)
+            counts2 = counts[:M2].clone()
+            KL2 = kernels.Kuu(Z[:M2].contiguous(), kern, jitter=0.0, diag_add=syn.noise_variance / counts2)
+            u2 = u[:M2].contiguous()
+            cgm.solve_with_stats(KL2, u2)
+            ((_, (c2steps, _)), t_cg2) = timed(lambda: cgm.solve_with_stats(KL2, u2))
+            it2_us = 1e3 * t_cg2 / max(int(c2steps), 1)
+            tri2_bytes = esize * (M2 * (M2 + 64) / 2.0)
+            d1_form = {"3": "register-resident: the whole solve in one launch, the upper triangle of A held on the chip "
+                            "(csrc/cg_dense1.hip), n <= 4096", "1": "two launches per iteration"}.get(
+                os.environ.get("MGP_CG_DENSE1", "3"), "MGP_CG_DENSE1=" + os.environ.get("MGP_CG_DENSE1", ""))
             tri_bytes = esize * (M * (M + 64) / 2.0)  # the upper triangle's 64 x 64 tiles: what an iteration streams
             cdgp = {"assign_and_stats_ms": t_assign, "assign_and_stats_first_call_ms": t_assign_first,
                     "kuu_lambda_ms": t_k, "kuu_lambda_first_call_ms": t_k_first,
                     "cg_iterations": int(csteps), "cg_ms": t_cg, "cg_us_per_iteration": it_us,
-                    "cg_hbm": {"bytes_per_iteration": tri_bytes, "GBps": tri_bytes / (it_us * 1e-6) / 1e9,
-                               "frac_of_8TBps": tri_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                               "note": "dense one-RHS CG, two launches per iteration (csrc/cg_dense1.hip); bytes = the "
-                                       "upper-triangle tiles of Kmm+Lambda actually read; includes the solve's start-up "
-                                       "and its polls every 25 iterations"},
+                    "cg_form": d1_form,
+                    "cg_hbm": {"bytes_per_iteration_if_streamed": tri_bytes,
+                               "equivalent_GBps": tri_bytes / (it_us * 1e-6) / 1e9,
+                               "equivalent_frac_of_8TBps": tri_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "dense one-RHS CG (csrc/cg_dense1.hip).  bytes = the upper-triangle tiles of "
+                                       "Kmm+Lambda, what the two-launch form streams from HBM in every iteration; the "
+                                       "register-resident form reads them ONCE per solve, so for it this is an equivalent "
+                                       "rate (what a streaming implementation would have to sustain), not traffic: its "
+                                       "iteration is bound by two hand-offs between resident workgroups, not by HBM.  "
+                                       "Wall time of the whole solve / steps, start-up included"},
+                    "cg_c2_size": {"M": M2, "cg_iterations": int(c2steps), "cg_ms": t_cg2, "cg_us_per_iteration": it2_us,
+                                   "equivalent_GBps": tri2_bytes / (it2_us * 1e-6) / 1e9},
+                    "probe_cg": {"columns": 64, "iterations": int(psteps), "ms": t_pcg, "us_per_iteration": p_us,
+                                 "tflops": p_flops / (p_us * 1e-6) / 1e12,
+                                 "frac_of_fp64_mfma_peak": p_flops / (p_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                 "GBps_on_A_read_once": p_bytes / (p_us * 1e-6) / 1e9,
+                                 "frac_of_8TBps": p_bytes / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                 "note": "64-column CG on Kmm+Lambda (skinny MFMA product + fused update): both rooflines "
+                                         "coincide near 27 us per iteration at M = 4096 (2.1 GFLOP at 78.6 TFLOP/s; "
+                                         "134 MB at 5 TB/s)"},
                     "cg_half_rz_final": float(cerr.max().item()),
                     "true_half_residual_sq": 0.5 * float((res * res).sum().item()),
                     "predict_mean_all_local_rows_ms": t_mean,

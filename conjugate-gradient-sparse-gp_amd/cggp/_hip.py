@@ -139,6 +139,7 @@ SIGNATURES = {
     # host-only entry points (cover tree, row F3)
     "mgp_host_last_error": (ctypes.c_char_p, []),
     "mgp_covertree_build": (_I, [_P, _L, _I, _D, _I, _I, _I, ctypes.POINTER(_P)]),
+    "mgp_covertree_build_device": (_I, [_P, _P, _P, _L, _I, _D, _I, _I, _I, ctypes.POINTER(_P)]),
     "mgp_covertree_destroy": (None, [_P]),
     "mgp_covertree_num_levels": (_I, [_P]),
     "mgp_covertree_level_size": (_L, [_P, _I]),

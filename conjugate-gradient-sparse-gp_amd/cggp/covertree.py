@@ -1,10 +1,13 @@
 """Cover-tree clustering (next row F3) -- host mirror of `cggp/covertree.py:13-179`.
 
-Same constructor and properties as the reference class; the construction itself is
-`mgp_covertree_build` in libmgp (host C++ over row indices, `csrc/covertree.cpp`).  As in the
-reference the `distance` argument is ignored and the Euclidean norm is used (`covertree.py:36-44`).
-`data` may be numpy arrays or torch tensors (device tensors are copied to the host once, the way
-the reference calls `.numpy()` in `optimize.py:25`).
+Same constructor and properties as the reference class; the construction itself is libmgp's:
+`mgp_covertree_build_device` when a GPU is present (the sequential acceptance of centres on the host, the
+four all-pairs-shaped passes -- seed balls, the rows a centre takes, Voronoi reassignment, r-neighbour test
+-- as device filters over X, `csrc/covertree_dev.hip`), `mgp_covertree_build` (host C++ over row indices,
+`csrc/covertree.cpp`) otherwise; the two give the same tree bit for bit.  As in the reference the
+`distance` argument is ignored and the Euclidean norm is used (`covertree.py:36-44`).  `data` may be numpy
+arrays or torch tensors (the host keeps a copy of x either way, as the reference calls `.numpy()` in
+`optimize.py:25`).
 """
 
 import ctypes
@@ -39,8 +42,21 @@ def _host(a):
 
 class CoverTree:
     def __init__(self, distance, data, spatial_resolution=None, num_levels=1, lloyds=True, voronoi=True,
-                 plotting=False):
+                 plotting=False, *, device=None):
+        """`device`: None = the GPU-assisted construction whenever a GPU is there (on the device of `data[0]` if
+        that is a CUDA tensor, else the current one), False = the host construction, a torch device = that GPU."""
         warnings.warn("Distance function will be ignored and instead the Euclidean norm will be used.")
+        dev = None
+        if device is not False and torch.cuda.is_available():
+            if isinstance(device, (torch.device, str)):
+                dev = torch.device(device)
+            elif isinstance(data[0], torch.Tensor) and data[0].is_cuda:
+                dev = data[0].device
+            else:
+                dev = torch.device("cuda", torch.cuda.current_device())
+        elif device not in (None, False):
+            raise RuntimeError("CoverTree(device=...) needs a GPU")
+        x_in = data[0]
         x, y = (_host(a) for a in data)
         if x.ndim != 2 or y.ndim != 2 or x.shape[0] != y.shape[0]:
             raise ValueError("data must be (x [N,D], y [N,Dy])")
@@ -51,8 +67,19 @@ class CoverTree:
         res = 0.0 if spatial_resolution is None else float(spatial_resolution)
         if spatial_resolution is not None and not res > 0.0:
             raise ValueError("spatial_resolution must be positive")
-        rc = lib.mgp_covertree_build(x64.ctypes.data, x.shape[0], x.shape[1], res, int(num_levels or 1),
-                                     int(bool(lloyds)), int(bool(voronoi)), ctypes.byref(handle))
+        if dev is not None:
+            hd = _hip.get_handle(dev)
+            if isinstance(x_in, torch.Tensor) and x_in.is_cuda and x_in.device == dev:
+                x_dev = x_in.detach().to(torch.float64).contiguous()
+            else:
+                x_dev = torch.from_numpy(x64).to(dev)
+            rc = lib.mgp_covertree_build_device(hd.h, x64.ctypes.data, _hip.ptr(x_dev), x.shape[0], x.shape[1], res,
+                                                int(num_levels or 1), int(bool(lloyds)), int(bool(voronoi)),
+                                                ctypes.byref(handle))
+        else:
+            rc = lib.mgp_covertree_build(x64.ctypes.data, x.shape[0], x.shape[1], res, int(num_levels or 1),
+                                         int(bool(lloyds)), int(bool(voronoi)), ctypes.byref(handle))
+        self.built_on = "device" if dev is not None else "host"
         if rc != 0:
             raise RuntimeError(f"mgp_covertree_build failed ({rc}): {lib.mgp_host_last_error().decode()}")
         try:

@@ -21,48 +21,64 @@
 #include <new>
 #include <vector>
 
-#include "../../include/mgp.h"
+#include "covertree.h"
 
 namespace {
 
 thread_local char g_err[256] = "";
 
-int host_fail(int code, const char* fmt, ...) {
+using Node = MgpCtNode;
+
+inline double dist(const double* p, const double* q, int D) { return mgp_ct_dist(p, q, D); }
+
+}  // namespace
+
+int mgp_ct_host_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
+#define host_fail mgp_ct_host_fail
 
-struct Node {
-  std::vector<double> point;
-  int parent = -1;             // node id
-  std::vector<int> children;   // node ids, creation order
-  std::vector<int> rnb;        // r-neighbours (node ids of the same level)
-  std::vector<int64_t> rows;   // data rows held
-  std::vector<int64_t> vor;    // accumulated Voronoi rows
-  bool has_vor = false;
-};
-
-inline double dist(const double* p, const double* q, int D) {
-  double s = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double t = p[d] - q[d];
-    s += t * t;
-  }
-  return std::sqrt(s);
-}
-
-}  // namespace
-
-struct mgp_covertree {
-  int D = 0;
-  int64_t N = 0;
+int mgp_ct_make_root(mgp_covertree* t, const double* x, int64_t N, int D, double spatial_resolution, int* num_levels_io,
+                     int voronoi) {
+  int num_levels = *num_levels_io;
+  t->D = D;
+  t->N = N;
+  t->nodes.emplace_back();
+  Node& root = t->nodes.back();
+  root.point.assign(D, 0.0);
+  for (int64_t i = 0; i < N; ++i)
+    for (int d = 0; d < D; ++d) root.point[d] += x[i * D + d];
+  for (int d = 0; d < D; ++d) root.point[d] /= (double)N;
   double max_radius = 0.0;
-  std::deque<Node> nodes;                // stable references while growing
-  std::vector<std::vector<int>> levels;  // node ids per level
-};
+  for (int64_t i = 0; i < N; ++i) {
+    const double r = dist(root.point.data(), x + i * D, D);
+    if (r > max_radius) max_radius = r;
+  }
+  if (spatial_resolution > 0.0) {
+    if (!(max_radius > 0.0))
+      return host_fail(MGP_E_BADARG, "covertree: all rows coincide, no level count for a resolution");
+    num_levels = (int)std::ceil(std::log2(max_radius / spatial_resolution)) + 1;
+    max_radius = spatial_resolution * std::ldexp(1.0, num_levels - 1);
+  }
+  if (num_levels < 1 || num_levels > 60)
+    return host_fail(MGP_E_BADARG, "covertree: %d levels (resolution larger than the data radius?)", num_levels);
+  t->max_radius = max_radius;
+  root.rows.resize(N);
+  for (int64_t i = 0; i < N; ++i) root.rows[i] = i;
+  root.rnb.push_back(0);
+  if (voronoi) {
+    root.vor = root.rows;
+    root.has_vor = true;
+  }
+  t->levels.assign(num_levels, {});
+  t->levels[0].push_back(0);
+  *num_levels_io = num_levels;
+  return MGP_OK;
+}
 
 extern "C" const char* mgp_host_last_error(void) { return g_err; }
 
@@ -74,41 +90,12 @@ extern "C" int mgp_covertree_build(const double* x, int64_t N, int D, double spa
   mgp_covertree* t = new (std::nothrow) mgp_covertree;
   if (!t) return host_fail(MGP_E_HIP, "covertree: out of memory");
   try {
-    t->D = D;
-    t->N = N;
-    t->nodes.emplace_back();
-    Node& root = t->nodes.back();
-    root.point.assign(D, 0.0);
-    for (int64_t i = 0; i < N; ++i)
-      for (int d = 0; d < D; ++d) root.point[d] += x[i * D + d];
-    for (int d = 0; d < D; ++d) root.point[d] /= (double)N;
-    double max_radius = 0.0;
-    for (int64_t i = 0; i < N; ++i) {
-      const double r = dist(root.point.data(), x + i * D, D);
-      if (r > max_radius) max_radius = r;
-    }
-    if (spatial_resolution > 0.0) {
-      if (!(max_radius > 0.0)) {
-        delete t;
-        return host_fail(MGP_E_BADARG, "covertree: all rows coincide, no level count for a resolution");
-      }
-      num_levels = (int)std::ceil(std::log2(max_radius / spatial_resolution)) + 1;
-      max_radius = spatial_resolution * std::ldexp(1.0, num_levels - 1);
-    }
-    if (num_levels < 1 || num_levels > 60) {
+    const int rc_root = mgp_ct_make_root(t, x, N, D, spatial_resolution, &num_levels, voronoi);
+    if (rc_root != MGP_OK) {
       delete t;
-      return host_fail(MGP_E_BADARG, "covertree: %d levels (resolution larger than the data radius?)", num_levels);
+      return rc_root;
     }
-    t->max_radius = max_radius;
-    root.rows.resize(N);
-    for (int64_t i = 0; i < N; ++i) root.rows[i] = i;
-    root.rnb.push_back(0);
-    if (voronoi) {
-      root.vor = root.rows;
-      root.has_vor = true;
-    }
-    t->levels.assign(num_levels, {});
-    t->levels[0].push_back(0);
+    const double max_radius = t->max_radius;
 
     std::vector<double> point(D);
     std::vector<int64_t> keep;

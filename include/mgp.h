@@ -291,6 +291,13 @@ typedef struct mgp_covertree mgp_covertree;
 const char* mgp_host_last_error(void);
 int mgp_covertree_build(const double* x, int64_t N, int D, double spatial_resolution, int num_levels, int lloyds,
                         int voronoi, mgp_covertree** out);
+/* The same construction -- the same tree, node for node and bit for bit -- with its four all-pairs-shaped passes (the
+ * ball of a seed, the rows a new centre takes, the per-level Voronoi reassignment, the r-neighbour test of the new
+ * centres) as device filters over `x_dev`, the fp64 device copy of the same [N, D] rows; the sequential acceptance of
+ * centres and every mean stay on the host (csrc/covertree_dev.hip).  For inputs where almost every node is an
+ * r-neighbour of every other (D >= ~6) the host version scans nearly all rows per centre. */
+int mgp_covertree_build_device(mgp_handle* h, const double* x, const double* x_dev, int64_t N, int D,
+                               double spatial_resolution, int num_levels, int lloyds, int voronoi, mgp_covertree** out);
 void mgp_covertree_destroy(mgp_covertree* t);
 int mgp_covertree_num_levels(const mgp_covertree* t);
 int64_t mgp_covertree_level_size(const mgp_covertree* t, int level);
