@@ -60,6 +60,10 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (kta && (atoi(kta) == 16 || atoi(kta) == 64)) h->kdense_ta = atoi(kta);
   const char* cd1 = getenv("MGP_CG_DENSE1");
   if (cd1) h->cg_dense1 = atoi(cd1);
+  if (getenv("MGP_CG_DENSE1_COLS")) {
+    const int c = atoi(getenv("MGP_CG_DENSE1_COLS"));
+    h->cg_dense1_cols = c < 1 ? 1 : (c > 8 ? 8 : c);
+  }
   const char* cpp = getenv("MGP_CG_PIPELINE_POLLS");
   if (cpp) h->poll_pipeline = atoi(cpp) != 0;
   const char* tm = getenv("MGP_TRI_MIN_N");

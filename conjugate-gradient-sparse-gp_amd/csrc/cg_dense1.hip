@@ -354,6 +354,256 @@ __device__ __forceinline__ void rs_step_row(T (&x)[16], int l) {
   }
 }
 
+// ------------------------------------------------------------------ round 4: 2 .. 8 right-hand sides on the tile scheme
+// The reference's default probe count is 5 (`CGGP(num_probes=5)`, cggp/models.py:286): every `prior_kl` and
+// `eval_logdet` of a training step is a 5-column CG on Kmm + Lambda.  Round 3 ran those through the skinny MFMA
+// product (the whole matrix read, a third of the matrix cores' columns used) + the fused update: 35 us per iteration
+// at n = 4096.  Here the two-launch iteration above carries BT columns: T reads each upper-triangle tile ONCE and
+// forms, per column, the direction on the fly, both tile products and the share of p.Ap; U -- one workgroup per
+// (chunk, column) -- is d1_update_kernel with a column index.  Same recurrence per column (:64-85), the reference's
+// `any` over the columns as stopping rule (:59-62), the same guards per column (:68, :79), sums in fixed order.
+template <typename T>
+__global__ __launch_bounds__(64) void d1m_init_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ b,
+                                                      const T* __restrict__ av, T* __restrict__ r,
+                                                      const T* __restrict__ dinv, T* __restrict__ cpart,
+                                                      T* __restrict__ scal, long n, int* __restrict__ stopw) {
+  const int l = threadIdx.x, col = blockIdx.y;
+  const long i = (long)blockIdx.x * 64 + l, off = (long)col * n;
+  T rv = 0, zv = 0;
+  if (i < n) {
+    rv = av ? b[off + i] - av[off + i] : b[off + i];
+    r[off + i] = rv;
+    zv = dinv ? rv * dinv[i] : rv;
+  }
+  const T prz = wave_allsum(zv * rv), prr = wave_allsum(rv * rv);
+  if (l == 0) {
+    T* cp = cpart + (long)col * 2 * CP;
+    cp[blockIdx.x] = prz;
+    cp[CP + blockIdx.x] = prr;
+    if (blockIdx.x == 0) {
+      scal[2 * col] = 0;
+      scal[2 * col + 1] = 0;
+      if (col == 0) {
+        ctrl->active = 1;
+        ctrl->iters = 0;
+        ctrl->ticket = 0;
+        ctrl->pad = 0;
+        stopw[0] = 0;
+        stopw[1] = 0;
+      }
+    }
+  }
+}
+
+// statistics per column + the gate for the host poll: one wave per column
+template <typename T>
+__global__ __launch_bounds__(512) void d1m_finish_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ cpart,
+                                                         T* __restrict__ rz, T* __restrict__ err,
+                                                         int* __restrict__ over, T thr, int max_it, int bt) {
+  __shared__ int any_s[8];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (w < bt) {
+    T s_rz, s_rr;
+    sum_shares(cpart + (long)w * 2 * CP, l, s_rz, s_rr);
+    if (l == 0) {
+      rz[w] = s_rz;
+      err[w] = (T)0.5 * s_rz;
+      const int a = ((T)0.5 * s_rr > thr) ? 1 : 0;
+      over[w] = a;
+      any_s[w] = a;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int q = 0; q < bt; ++q) any |= any_s[q];
+    if (ctrl->active) ctrl->active = (any && ctrl->iters < max_it) ? 1 : 0;
+  }
+}
+
+template <typename T, bool JAC, int BT>
+__global__ __launch_bounds__(256) void d1m_tile_kernel(const MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ A,
+                                                       long n, const T* __restrict__ r, const T* __restrict__ dinv,
+                                                       const T* __restrict__ p_old, T* __restrict__ p_new,
+                                                       const T* __restrict__ cpart, T* __restrict__ scal, int k,
+                                                       const int2* __restrict__ tab, T* __restrict__ Q, int nt,
+                                                       T* __restrict__ tpart, long ntiles, T thr, T min_float,
+                                                       int max_it, int* __restrict__ stopw) {
+  if (ctrl->active == 0 || stopw[(k + 1) & 1] != 0) {  // see d1_tile_kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) stopw[k & 1] = 1;
+    return;
+  }
+  constexpr int TS = 64;
+  __shared__ T colp[BT][4][TS];
+  __shared__ T wsum[BT][4];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const long b = blockIdx.x;
+  const int2 ij = tab[b];
+  const int I = ij.x, J = ij.y;
+  const long r0 = (long)I * TS + 16 * w, c = (long)J * TS + l, ci = (long)I * TS + l;
+  const long cj = c < n ? c : n - 1, cic = ci < n ? ci : n - 1;
+  // the recurrence's operands of every column first (L2-resident), the tile's 16 loads behind them (d1_tile_kernel)
+  T z0[BT], z1[BT], q0[BT], q1[BT], rj[BT], poj[BT], ri[BT], poi[BT], rzo[BT];
+#pragma unroll
+  for (int e = 0; e < BT; ++e) {
+    const T* cp = cpart + (long)e * 2 * CP;
+    z0[e] = cp[l], z1[e] = cp[64 + l], q0[e] = cp[CP + l], q1[e] = cp[CP + 64 + l];
+    rj[e] = r[(long)e * n + cj], poj[e] = p_old[(long)e * n + cj];
+    ri[e] = r[(long)e * n + cic], poi[e] = p_old[(long)e * n + cic];
+    rzo[e] = scal[2 * e + (k & 1)];
+  }
+  const T dj = JAC ? dinv[cj] : (T)1, di = JAC ? dinv[cic] : (T)1;
+  const int it = ctrl->iters;
+  __builtin_amdgcn_sched_barrier(0);
+  T a[16];
+  {
+    const T* row = A + (r0 < n ? r0 : n - 1) * n + cj;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      a[q] = *row;
+      row += (r0 + q + 1 < n) ? n : 0;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // per column: rz, ||r||^2 of the current residual, beta, the direction's entries -- while the tile is in flight
+  T pj[BT], pi[BT], rzn[BT];
+  bool any = false;
+#pragma unroll
+  for (int e = 0; e < BT; ++e) {
+    rzn[e] = wave_allsum_valu(z0[e] + z1[e]);  // the same bits as wave_allsum (commutative butterfly)
+    const T rr_new = wave_allsum_valu(q0[e] + q1[e]);
+    any = any || (T)0.5 * rr_new > thr;
+  }
+  const bool live = any && it < max_it;  // :59-62: `any` over the columns
+  if (b == 0 && t == 0) stopw[k & 1] = live ? 0 : 1;
+#pragma unroll
+  for (int e = 0; e < BT; ++e) {
+    if (b == 0 && t == 0 && live) scal[2 * e + ((k + 1) & 1)] = rzn[e];
+    const bool drop = rzo[e] <= min_float;  // :79, per column
+    const T beta = drop ? (T)0 : rzn[e] / rzo[e];
+    const T zj = JAC ? rj[e] * dj : rj[e], zi = JAC ? ri[e] * di : ri[e];
+    T vj = drop ? zj : mgp_fma(beta, poj[e], zj);
+    T vi = drop ? zi : mgp_fma(beta, poi[e], zi);
+    pj[e] = c < n ? vj : (T)0;
+    pi[e] = ci < n ? vi : (T)0;
+    if (live && I == J && w == 0 && c < n) p_new[(long)e * n + c] = pj[e];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q] = (r0 + q < n && c < n) ? a[q] : (T)0;
+#pragma unroll
+  for (int e = 0; e < BT; ++e) {
+    // Cross-lane steps on the vector ALU (permlane swaps / DPP), not ds_bpermute: with several columns per tile the LDS
+    // crossbar was the bound -- 72 bpermutes per tile, wave and column, ~7 us per column at n = 4096 against ~5 us this
+    // way (alternating the columns between the two pipes was measured too: no better).  The additions are the same.
+    T x[16];
+    T cs = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      cs = mgp_fma(a[q], mgp_read_lane(pi[e], 16 * w + q), cs);
+      x[q] = rs_swap_add<true>(a[q] * pj[e], a[q + 8] * pj[e]);  // rows q and q + 8 meet across lane bit 32
+    }
+#pragma unroll
+    for (int q = 8; q < 16; ++q) cs = mgp_fma(a[q], mgp_read_lane(pi[e], 16 * w + q), cs);
+    colp[e][w][l] = cs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = rs_swap_add<false>(x[q], x[q + 4]);  // lane bit 16
+    rs_step_row<T, 2, 8>(x, l);
+    rs_step_row<T, 1, 4>(x, l);
+    T s = x[0];
+    s += lane_xor_row<2>(s);
+    s += lane_xor_row<1>(s);  // lane l: (A_IJ p_J)[16 w + (l >> 2)]
+    const long i = r0 + (l >> 2);
+    if (live && (l & 3) == 0 && i < n) Q[((long)e * nt + J) * n + i] = s;
+    const T prow = __shfl(pi[e], 16 * w + (l >> 2), 64);
+    const T u = wave_allsum_valu((l & 3) == 0 ? s * prow : (T)0);
+    if (l == 0) wsum[e][w] = u;
+  }
+  __syncthreads();
+  if (live && I != J) {
+    // column sums: BT x 64 outputs over the 256 threads
+    for (int o = t; o < BT * TS; o += 256) {
+      const int e = o >> 6, cc = o & 63;
+      const T sc = (colp[e][0][cc] + colp[e][1][cc]) + (colp[e][2][cc] + colp[e][3][cc]);
+      const long ic2 = (long)J * TS + cc;
+      if (ic2 < n) Q[((long)e * nt + I) * n + ic2] = sc;
+    }
+  }
+  if (live && t < BT) {
+    const T tot = (wsum[t][0] + wsum[t][1]) + (wsum[t][2] + wsum[t][3]);
+    tpart[(long)t * ntiles + b] = I == J ? tot : tot + tot;
+  }
+}
+
+// U for column blockIdx.y: d1_update_kernel's arithmetic on that column's slots, shares and vectors
+template <typename T, bool JAC, int NT, int PER, int TPM>
+__global__ __launch_bounds__(NT) void d1m_update_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ Q, int nt,
+                                                        const T* __restrict__ tpart, long ntiles,
+                                                        const T* __restrict__ scal, int k, const T* __restrict__ p,
+                                                        T* __restrict__ v, T* __restrict__ r,
+                                                        const T* __restrict__ dinv, T* __restrict__ cpart, long n,
+                                                        T min_float, const int* __restrict__ stopw) {
+  if (ctrl->active == 0 || stopw[k & 1] != 0) return;
+  constexpr int NW = NT / 64;
+  __shared__ T part[NW][64];
+  __shared__ T red[NW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = blockIdx.y;
+  const long c = blockIdx.x, off = (long)col * n;
+  const long i = c * 64 + lane;
+  const long ic = i < n ? i : n - 1;
+  const T* Qc = Q + (long)col * nt * n;
+  const T* tpc = tpart + (long)col * ntiles;
+  const int kb = wave * PER;
+  T sl[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int kk = kb + q < nt ? kb + q : nt - 1;
+    sl[q] = Qc[(long)kk * n + ic];
+  }
+  T tp[TPM];
+#pragma unroll
+  for (int m = 0; m < TPM; ++m) {
+    const long e = (long)m * NT + t;
+    tp[m] = tpc[e < ntiles ? e : ntiles - 1];
+  }
+  const T pc = p[off + ic], rc = r[off + ic], vc = v[off + ic];
+  const T dc = JAC ? dinv[ic] : (T)1;
+  const T rz_prev = scal[2 * col + ((k + 1) & 1)];
+  T d = 0;
+#pragma unroll
+  for (int m = 0; m < TPM; ++m) d += ((long)m * NT + t < ntiles) ? tp[m] : (T)0;
+  d = wave_allsum(d);
+  if (lane == 0) red[wave] = d;
+  T s = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) s += (kb + q < nt) ? sl[q] : (T)0;
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0) return;
+  d = red[0];
+#pragma unroll
+  for (int q = 1; q < NW; ++q) d += red[q];
+  const T gamma = (d <= min_float) ? (T)0 : rz_prev / d;  // :66-68
+  T a = part[0][lane];
+#pragma unroll
+  for (int q = 1; q < NW; ++q) a += part[q][lane];
+  const T vn = mgp_fma(gamma, pc, vc);   // :69
+  const T rn = mgp_fma(-gamma, a, rc);   // :76
+  const T zn = JAC ? rn * dc : rn;       // :77
+  const bool ok = i < n;
+  if (ok) {
+    v[off + i] = vn;
+    r[off + i] = rn;
+  }
+  const T prz = wave_allsum(ok ? zn * rn : (T)0), prr = wave_allsum(ok ? rn * rn : (T)0);
+  if (lane == 0) {
+    T* cp = cpart + (long)col * 2 * CP;
+    cp[c] = prz;
+    cp[CP + c] = prr;
+    if (c == 0 && col == 0) ctrl->iters = ctrl->iters + 1;
+  }
+}
+
 // workgroup barrier that orders LDS only (no wait for vector-memory operations in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -731,17 +981,28 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
 
 template <typename T>
 int d1_layout(MgpDense1* st, void* arena, long n) {
-  // arena: tpart[ntiles] | cpart[2 CP] | scal[2] | pb[2][n] | zpub[n] | hand-off error word (128-byte line of its own)
+  // arena (bt = columns): tpart[bt][ntiles] | cpart[bt][2 CP] | scal[bt][2] | pb[2][bt][n] | zpub[n] |
+  //        (bt > 1) the slots Q[bt][nt][n] | hand-off words (a 128-byte line of their own: error word, two stop words)
   //        | granules of the register-resident form: Qg[nt n] | wpg[256] | cg[128] | zg[n]  (x W 8-byte words each)
-  const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
+  const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2, bt = st->bt;
   T* a = (T*)arena;
   st->tpart = a;
-  st->cpart = a + ntiles;
-  st->scal = a + ntiles + 2 * CP;
-  st->pb[0] = a + ntiles + 2 * CP + 2;
-  st->pb[1] = a + ntiles + 2 * CP + 2 + n;
-  st->zpub = a + ntiles + 2 * CP + 2 + 2 * n;
-  st->sync = (void*)(((uintptr_t)(a + ntiles + 2 * CP + 2 + 3 * n) + 127) & ~(uintptr_t)127);
+  a += bt * ntiles;
+  st->cpart = a;
+  a += bt * 2 * CP;
+  st->scal = a;
+  a += bt * 2;
+  st->pb[0] = a;
+  st->pb[1] = a + bt * n;
+  a += 2 * bt * n;
+  st->zpub = a;
+  a += n;
+  st->Qm = nullptr;
+  if (bt > 1) {
+    st->Qm = a;
+    a += bt * nt * n;
+  }
+  st->sync = (void*)(((uintptr_t)a + 127) & ~(uintptr_t)127);
   st->gran = (char*)st->sync + 128;
   return MGP_OK;
 }
@@ -753,10 +1014,11 @@ static size_t d1_gran_bytes(int dtype, long n) {
 
 }  // namespace
 
-size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n) {
+size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n, int64_t bt) {
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
-  return (size_t)(ntiles + 2 * CP + 2 + 3 * n) * mgp_elem(dtype) + 128 + 128 +
-         (mgp_dense1_persist_eligible(h, n) ? d1_gran_bytes(dtype, n) : 0) + 64;
+  size_t e = (size_t)(bt * (ntiles + 2 * CP + 2 + 2 * n) + n);
+  if (bt > 1) e += (size_t)bt * nt * n;
+  return e * mgp_elem(dtype) + 128 + 128 + ((bt == 1 && mgp_dense1_persist_eligible(h, n)) ? d1_gran_bytes(dtype, n) : 0) + 64;
 }
 
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n) {
@@ -773,8 +1035,9 @@ bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n) {
 
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
-                     int64_t max_it, int persist) {
+                     int64_t max_it, int persist, int bt) {
   st->dtype = dtype;
+  st->bt = bt;
   st->A = A;
   st->n = n;
   st->V = V;
@@ -789,11 +1052,24 @@ int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int
   st->persist = persist;
   if (dtype == MGP_F64) d1_layout<double>(st, arena, n);
   else d1_layout<float>(st, arena, n);
-  MGP_HIP(h, hipMemsetAsync(st->cpart, 0, 2 * CP * mgp_elem(dtype), h->stream));  // shares of chunks beyond nt stay 0
+  MGP_HIP(h, hipMemsetAsync(st->cpart, 0, (size_t)bt * 2 * CP * mgp_elem(dtype), h->stream));  // shares of chunks beyond nt stay 0
   // the hand-off error word and -- a tag left by an earlier solve must never match an epoch of this one -- every granule
   MGP_HIP(h, hipMemsetAsync(st->sync, 0, 128 + (persist ? d1_gran_bytes(dtype, n) : 0), h->stream));
   // the product's slots and the tile table (dense.hip owns both)
   MGP_TRY(mgp_symm_gemv_tri_prepare(h, dtype, n, &st->Q, &st->tab));
+  if (bt > 1) {
+    const dim3 g((unsigned)st->nt, (unsigned)bt);
+    if (dtype == MGP_F64)
+      hipLaunchKernelGGL((d1m_init_kernel<double>), g, dim3(64), 0, h->stream, ctrl, (const double*)B, (const double*)av,
+                         (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal, (long)n,
+                         (int*)st->sync + 1);
+    else
+      hipLaunchKernelGGL((d1m_init_kernel<float>), g, dim3(64), 0, h->stream, ctrl, (const float*)B, (const float*)av,
+                         (float*)r, (const float*)dinv, (float*)st->cpart, (float*)st->scal, (long)n,
+                         (int*)st->sync + 1);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
+  }
   if (dtype == MGP_F64)
     hipLaunchKernelGGL((d1_init_kernel<double>), dim3((unsigned)st->nt), dim3(64), 0, h->stream, ctrl, (const double*)B,
                        (const double*)av, (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal,
@@ -898,8 +1174,51 @@ static int d1_step_t(mgp_handle* h, const MgpDense1* st, long k) {
   return MGP_OK;
 }
 
+template <typename T, bool JAC, int BT>
+static int d1m_step_t(mgp_handle* h, const MgpDense1* st, long k) {
+  const int kk = (int)(k & 1);
+  const T* p_old = (const T*)st->pb[(k + 1) & 1];
+  T* p_new = (T*)st->pb[k & 1];
+  int* stopw = (int*)st->sync + 1;
+  hipLaunchKernelGGL((d1m_tile_kernel<T, JAC, BT>), dim3((unsigned)st->ntiles), dim3(256), 0, h->stream, st->ctrl,
+                     (const T*)st->A, (long)st->n, (const T*)st->r, (const T*)st->dinv, p_old, p_new,
+                     (const T*)st->cpart, (T*)st->scal, kk, (const int2*)st->tab, (T*)st->Qm, st->nt, (T*)st->tpart,
+                     st->ntiles, (T)st->thr, (T)st->min_float, st->max_it, stopw);
+  MGP_LAUNCH_CHECK(h);
+  const dim3 g((unsigned)st->nt, (unsigned)BT);
+#define MGP_D1MU(NTV, PERV, TPMV)                                                                                    \
+  hipLaunchKernelGGL((d1m_update_kernel<T, JAC, NTV, PERV, TPMV>), g, dim3(NTV), 0, h->stream, st->ctrl,               \
+                     (const T*)st->Qm, st->nt, (const T*)st->tpart, st->ntiles, (const T*)st->scal, kk,               \
+                     (const T*)p_new, (T*)st->V, (T*)st->r, (const T*)st->dinv, (T*)st->cpart, (long)st->n,           \
+                     (T)st->min_float, (const int*)stopw)
+  if (st->nt <= 32) MGP_D1MU(256, 8, 3);
+  else if (st->nt <= 64) MGP_D1MU(256, 16, 9);
+  else MGP_D1MU(512, 16, 17);
+#undef MGP_D1MU
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
+template <typename T, bool JAC>
+static int d1m_step_bt(mgp_handle* h, const MgpDense1* st, long k) {
+  switch (st->bt) {
+    case 2: return d1m_step_t<T, JAC, 2>(h, st, k);
+    case 3: return d1m_step_t<T, JAC, 3>(h, st, k);
+    case 4: return d1m_step_t<T, JAC, 4>(h, st, k);
+    case 5: return d1m_step_t<T, JAC, 5>(h, st, k);
+    case 6: return d1m_step_t<T, JAC, 6>(h, st, k);
+    case 7: return d1m_step_t<T, JAC, 7>(h, st, k);
+    default: return d1m_step_t<T, JAC, 8>(h, st, k);
+  }
+}
+
 // enqueue iteration k (k = 1, 2, ...): T_k, U_k
 int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k) {
+  if (st->bt > 1) {
+    if (st->dtype == MGP_F64)
+      return st->dinv ? d1m_step_bt<double, true>(h, st, k) : d1m_step_bt<double, false>(h, st, k);
+    return st->dinv ? d1m_step_bt<float, true>(h, st, k) : d1m_step_bt<float, false>(h, st, k);
+  }
   if (st->dtype == MGP_F64)
     return st->dinv ? d1_step_t<double, true>(h, st, k) : d1_step_t<double, false>(h, st, k);
   return st->dinv ? d1_step_t<float, true>(h, st, k) : d1_step_t<float, false>(h, st, k);
@@ -907,6 +1226,16 @@ int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k) {
 
 // statistics (rz, err, over) and the gate word for the host poll
 int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* over) {
+  if (st->bt > 1) {
+    if (st->dtype == MGP_F64)
+      hipLaunchKernelGGL((d1m_finish_kernel<double>), dim3(1), dim3(512), 0, h->stream, st->ctrl,
+                         (const double*)st->cpart, (double*)rz, (double*)err, over, (double)st->thr, st->max_it, st->bt);
+    else
+      hipLaunchKernelGGL((d1m_finish_kernel<float>), dim3(1), dim3(512), 0, h->stream, st->ctrl,
+                         (const float*)st->cpart, (float*)rz, (float*)err, over, (float)st->thr, st->max_it, st->bt);
+    MGP_LAUNCH_CHECK(h);
+    return MGP_OK;
+  }
   if (st->dtype == MGP_F64)
     hipLaunchKernelGGL((d1_finish_kernel<double>), dim3(1), dim3(64), 0, h->stream, st->ctrl,
                        (const int*)st->sync, (const double*)st->cpart, (double*)rz, (double*)err,
@@ -918,3 +1247,4 @@ int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* ov
   MGP_LAUNCH_CHECK(h);
   return MGP_OK;
 }
+

@@ -48,6 +48,9 @@ struct mgp_handle {
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   hipEvent_t poll_ev[2] = {nullptr, nullptr};  // one polled batch of the dense one-RHS CG in flight (cg.hip)
+  // most right-hand sides the tile scheme takes (MGP_CG_DENSE1_COLS: 1 = one only, as round 3; up to 8); 0 = by size,
+  // where it was measured faster than the skinny product + fused update: 4 for n <= 4096, 6 above
+  int cg_dense1_cols = 0;
   bool d1_persist_off = false;  // set for the retry of a solve whose register-resident launch reported a timed-out hand-off
   int poll_pipeline = 1;  // MGP_CG_PIPELINE_POLLS=0: drain the stream at every poll (round 3)
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
@@ -259,18 +262,19 @@ struct MgpDense1 {
   void *V = nullptr, *r = nullptr, *Q = nullptr, *tpart = nullptr, *cpart = nullptr, *scal = nullptr;
   void* pb[2] = {nullptr, nullptr};
   // register-resident form (cg_dense1.hip, round 4): published z, the workgroups' shares of p.Ap, the hand-off flags
-  int persist = 0;
+  int persist = 0, bt = 1;  // bt: right-hand sides (2..8: the multi-column kernels, their slots in Qm)
+  void* Qm = nullptr;
   void *zpub = nullptr, *sync = nullptr, *gran = nullptr;
   const void* tab = nullptr;
   MgpCgCtrl* ctrl = nullptr;
   double thr = 0, min_float = 0;
 };
-size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n);
+size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n, int64_t bt);
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n);
 bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n);
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
-                     int64_t max_it, int persist);
+                     int64_t max_it, int persist, int bt);
 int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st);
 int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k);
 int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* over);

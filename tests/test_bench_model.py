@@ -34,6 +34,18 @@ def test_model_file_covers_every_single_gpu_bench_config():
     assert c4["active_valu_quadcycles_per_wave_pair"] > 1.2 * c4["valu_instructions_per_pair"]
 
 
+def test_model_belongs_to_the_kernel_sources_of_this_tree():
+    """The PMC counters describe ONE version of the sweep kernels: the model file names the git blob hashes of the
+    sources they were taken with, bench.py reports a mismatch as `roofline.model.stale`, and this test fails on it
+     -- after editing csrc/sweep.hip or csrc/mgp_math.h re-run tools/pmc_sweep.sh + tools/make_valu_model.py."""
+    import hashlib
+    m = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_model.json")))
+    assert m["measured_sources"], "the model file must name the sources it was measured with"
+    for path, sha in m["measured_sources"].items():
+        data = open(os.path.join(ROOT, path), "rb").read()
+        assert hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest() == sha, f"{path} edited since the PMC passes"
+
+
 def test_bench_constants_and_recomputation():
     b = _bench()
     assert b.NUM_SIMDS == 1024 and b.MAX_CLOCK_HZ == 2.4e9
@@ -42,7 +54,7 @@ def test_bench_constants_and_recomputation():
     assert abs(b.FP64_VECTOR_PEAK_TFLOPS - 1024 * 16 * 2 * 2.4e9 / 1e12) < 0.1
     assert b.EXECUTED_FLOPS_PER_PAIR[(8, "se")](8, 1) == 28 and b.SURVEY_FLOPS_PER_PAIR(8, 1) == 61
     # the committed line of this round recomputes from the model file
-    line_path = os.path.join(ROOT, "profiles", "r03_final_bench.json")
+    line_path = os.path.join(ROOT, "profiles", "r04_final_bench.json")
     if os.path.exists(line_path):
         d = json.load(open(line_path))
         r = d["roofline"]

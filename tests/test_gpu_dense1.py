@@ -195,6 +195,76 @@ def test_one_column_agrees_with_the_several_column_path():
     assert torch.equal(s1, s1b)
 
 
+@pytest.mark.parametrize("n", [1024, 2050, 4096, 8000])
+@pytest.mark.parametrize("Bt", [2, 5, 8])
+def test_several_columns_on_the_tile_scheme(n, Bt):
+    """2 .. 8 right-hand sides (the reference's default num_probes = 5, cggp/models.py:286): the two-launch tile scheme
+    with BT columns (csrc/cg_dense1.hip, d1m_*) where it is the faster route (Bt <= 4 at n <= 4096, <= 6 above; every
+    BT up to 8 is forced through it in test_every_form_...), the skinny product + fused update otherwise -- either
+    way: k steps against the oracle, column by column; the `any`
+    stopping rule (:59-62) -- all columns iterate until the slowest one is under the threshold; run-to-run identity;
+    and the same columns one at a time through the one-column forms."""
+    from cggp.conjugate_gradient import JacobiPreconditioner, conjugate_gradient
+    A, _ = problem(n, seed=n + Bt)
+    rng = np.random.default_rng(Bt)
+    rhs = rng.standard_normal((Bt, n)) * (10.0 ** rng.integers(-3, 3, (Bt, 1)))  # columns of very different size
+    for k in (1, 4, 7):
+        sol, (steps, err) = conjugate_gradient(T(A), T(rhs), None, 0.0, max_iterations=k, max_steps_cycle=k + 1)
+        o_sol, (o_steps, o_err) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), 0.0, max_iterations=k,
+                                                         max_steps_cycle=k + 1)
+        assert int(steps) == k == o_steps and sol.shape == (Bt, n) and err.shape == (Bt, 1)
+        for b in range(Bt):
+            assert relerr(sol[b], o_sol[b]) < 1e-9, (k, b)
+            assert abs(float(err[b]) - float(o_err[b, 0])) / float(o_err[b, 0]) < 1e-8
+    again, _ = conjugate_gradient(T(A), T(rhs), None, 0.0, max_iterations=7, max_steps_cycle=8, check_every=3)
+    assert torch.equal(sol, again)
+    # a converged solve: the step count is that of the slowest column, every column meets the rule on its TRUE residual
+    thr = 1e-8
+    s, (ks, es) = conjugate_gradient(T(A), T(rhs), None, thr, max_iterations=n, max_steps_cycle=n + 1, check_every=16)
+    o_s, (o_ks, _) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), thr, max_iterations=n, max_steps_cycle=n + 1)
+    assert int(ks) < n and abs(int(ks) - o_ks) <= max(3, o_ks // 20)
+    res = rhs - s.cpu().numpy() @ A
+    assert np.all(0.5 * np.sum(res * res, axis=1) <= thr * (1 + 1e-6) + 1e-16)
+    # Jacobi + an initial solution, three steps
+    if n <= 4096:
+        v0 = 0.01 * rng.standard_normal((Bt, n))
+        sj, (kj, ej) = conjugate_gradient(T(A), T(rhs), T(v0), 0.0, JacobiPreconditioner(), max_iterations=3,
+                                          max_steps_cycle=4)
+        o_sj, _ = ocg.conjugate_gradient(A, rhs, v0, 0.0, ocg.JacobiPreconditioner(), max_iterations=3, max_steps_cycle=4)
+        assert relerr(sj, o_sj) < 1e-9
+
+
+def test_every_form_of_the_dense_cg_gives_the_oracle_steps():
+    """The forms are chosen when the handle is made (MGP_CG_DENSE1 = 3: register-resident for n <= 4096, 1: two launches
+    per iteration; MGP_CG_DENSE1_COLS = 1: several columns through the skinny product as in round 3): the stress
+    script -- random n, steps, Jacobi, initial solutions, fp32, each case against the several-column kernels -- and a
+    k-step comparison with the oracle, once per form, each in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+        "from oracle import cg as ocg\n"
+        "from cggp.conjugate_gradient import conjugate_gradient\n"
+        "rng = np.random.default_rng(5)\n"
+        "for n, Bt in ((1500, 1), (4096, 1), (2048, 3), (6000, 1), (1500, 8), (4096, 5)):\n"
+        "    Q = rng.standard_normal((n, 16)); A = Q @ Q.T / 16 + np.diag(0.5 + rng.random(n)); b = rng.standard_normal((Bt, n))\n"
+        "    s, (k, e) = conjugate_gradient(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), None, 0.0, max_iterations=6, max_steps_cycle=7)\n"
+        "    o, _ = ocg.conjugate_gradient(A, b, np.zeros((Bt, n)), 0.0, max_iterations=6, max_steps_cycle=7)\n"
+        "    assert int(k) == 6 and np.max(np.abs(s.cpu().numpy() - o)) / np.max(np.abs(o)) < 1e-9, (n, Bt)\n"
+        "print('FORM_OK')\n" % (root, os.path.join(root, "conjugate-gradient-sparse-gp_amd")))
+    for env in ({"MGP_CG_DENSE1": "1"}, {"MGP_CG_DENSE1": "3"}, {"MGP_CG_DENSE1_COLS": "1"}, {"MGP_CG_DENSE1_COLS": "8"},
+                {"MGP_CG_DENSE1": "0"},
+                {"MGP_CG_PIPELINE_POLLS": "0", "MGP_CG_DENSE1": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0 and "FORM_OK" in out.stdout, (env, out.stderr[-1500:])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_dense1.py"), "40", "7"],
+                         env=dict(os.environ, MGP_CG_DENSE1_COLS="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "cases ok" in out.stdout, out.stderr[-1500:]
+
+
 def test_fp32():
     from cggp.conjugate_gradient import conjugate_gradient
     n = 2048
