@@ -458,7 +458,7 @@ def main():
                     "predict_mean_all_local_rows_ms": t_mean,
                     "prior_kl_64_probes_ms": t_kl, "prior_kl_64_probes_first_call_ms": t_kl_first, "prior_kl": kl,
                     "logdet_gradient_64_probes_ms": t_ldg,
-                    "probe_cg_iterations": int(cgm.last_stats[0])}
+                    "probe_cg_iterations": int(psteps)}
             # predictive VARIANCE of every local row (models.py:340, SURVEY row M3 "dominant cost today"), both ways
             B = 4096
             mdl.num_probes = None
