@@ -699,7 +699,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
                                                          T* __restrict__ r, T* __restrict__ v,
                                                          const T* __restrict__ dinv, T* __restrict__ cpart,
                                                          const int2* __restrict__ tab, T thr, T min_float, int max_it,
-                                                         unsigned long long* __restrict__ trace) {
+                                                         int first_poll_sleep, unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
   const int t = threadIdx.x, l = t & 63;
@@ -903,6 +903,9 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
       if (w == 11) {
         T tp[4] = {0, 0, 0, 0};
         bool ok = false;
+        // not at once: a poll issued the moment this workgroup has published is served before the slowest producer's
+        // store has landed, and the next one costs a whole round trip more
+        for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
         for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
           bool mine = true;
 #pragma unroll
@@ -974,6 +977,213 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
   if (w == 0 && own >= 0 && l == 0) {
     cpart[own] = shOwn[0];
     cpart[CP + own] = shOwn[1];
+  }
+  if (fail_s && t == 0) *pb.err = 1;
+  if (me == 0 && t == 0) ctrl->iters = k;
+}
+
+// ------------------------------------------------------------------ n <= 2048: the FULL matrix on the chip
+// At nt <= 32 tile rows all nt x nt tiles fit (1024 tiles, four per workgroup of 1024 threads), and a full tile row /
+// column set removes the expensive half of the triangle scheme: workgroup (J, rg) holds the tiles (I, J) of its row
+// group rg (up to four tile rows I, one per four-wave group) and forms ONLY the lane-local product
+//     y_J[c] += sum_r A[I rows r][c] * p_I[r]     (= (A_JI p_I)[c] by symmetry: lane = column, no cross-lane step),
+// sums its four tiles in LDS and publishes ONE 64-vector per workgroup -- a chunk's (A p)_J is the sum of R = G / nt
+// such vectors (8 at nt = 32, against 32 slots in the triangle scheme), and the owner of chunk J polls them and the
+// workgroups' shares of p.Ap in the SAME round trip.  Hand-offs, epochs, bounds and fail-over as in d1_persist_kernel.
+template <typename T, bool JAC>
+__global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
+                                                              const T* __restrict__ A, long n, int nt, int R, int rpg,
+                                                              T* __restrict__ r, T* __restrict__ v,
+                                                              const T* __restrict__ dinv, T* __restrict__ cpart,
+                                                              T thr, T min_float, int max_it, int first_poll_sleep,
+                                                              unsigned long long* __restrict__ trace) {
+  constexpr int TS = 64;
+  constexpr int W = Gran<T>::W;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..15
+  const int q = w >> 2, wq = w & 3;                       // four-wave group = tile of the workgroup, wave in the group
+  const int me = (int)blockIdx.x;
+  auto stamp = [&](int it, int point) {
+    if (trace != nullptr && t == 0 && blockIdx.x < 2 && it < 64)
+      trace[((long)blockIdx.x * 64 + it) * 8 + point] = wall_clock64();
+  };
+  const int nact = nt * R;  // workgroups with tiles; the rest of the grid leaves at once
+  if (me >= nact) return;
+  const int J = me / R, rg = me - J * R;
+  const int I = rg * rpg + q;               // tile row of this group
+  const bool have = q < rpg && I < nt;      // uniform per group
+  const bool owner = rg == 0;               // of chunk J
+  __shared__ T pJ[TS], pI[4][TS];
+  __shared__ T colp[4][4][TS];
+  __shared__ T rOwn[TS], vOwn[TS], dOwn[TS], shOwn[2], apOwn[2][TS];
+  __shared__ T sh_s[3];
+  __shared__ int fail_s;
+  if (t == 0) fail_s = 0;
+  // ---- the group's tile, once: rows 16 wq .. 16 wq + 15 of tile (I, J), lane = column; ragged edges are zeros
+  T a[16];
+  {
+    const long r0 = (long)(have ? I : 0) * TS + 16 * wq, c = (long)J * TS + l;
+    const long cj = c < n ? c : n - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long row = r0 + e < n ? r0 + e : n - 1;
+      const T x = A[row * n + cj];
+      a[e] = (have && r0 + e < n && c < n) ? x : (T)0;
+    }
+  }
+  const long oi = (long)J * TS + l;  // element of chunk J
+  const bool ook = oi < n;
+  if (w == 0 && owner) {
+    rOwn[l] = ook ? r[oi] : (T)0;
+    vOwn[l] = ook ? v[oi] : (T)0;
+    dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
+    if (l == 0) {
+      shOwn[0] = cpart[J];
+      shOwn[1] = cpart[CP + J];
+    }
+  }
+  T rz_old = 0;
+  int k = 0;
+  __syncthreads();
+  while (true) {
+    long kz = 0;  // see d1_persist_kernel
+    asm volatile("" : "+s"(kz));
+    stamp(k, 0);
+    // ================================================================= B_k
+    const unsigned eb = (unsigned)k + 1u;
+    T zv = 0;  // wave (q, 0): z of the group's tile row I; wave 1: z of chunk J
+    {
+      const bool duty = w == 0 || w == 1 || (wq == 2 && have);
+      T z0 = 0, q0 = 0;
+      bool ok = !duty;
+      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+        bool mine = true;
+        if (w == 0) {
+          if (l < nt) {
+            mine = Gran<T>::load(pb.cg + (long)(l + kz) * W, eb, z0) && mine;
+            mine = Gran<T>::load(pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
+          }
+        } else if (w == 1) {
+          if (ook) mine = Gran<T>::load(pb.zg + (oi + kz) * W, eb, zv) && mine;
+        } else {
+          const long e = (long)I * TS + l + kz;
+          if (e < n) mine = Gran<T>::load(pb.zg + e * W, eb, zv) && mine;
+        }
+        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok && l == 0) fail_s = 1;
+      if (w == 0) {
+        const T a_rz = wave_allsum_valu(z0), a_rr = wave_allsum_valu(q0);
+        if (l == 0) {
+          sh_s[0] = a_rz;
+          sh_s[1] = a_rr;
+        }
+      }
+    }
+    __syncthreads();
+    stamp(k, 1);
+    if (fail_s) break;
+    const T rz_new = sh_s[0], rr_new = sh_s[1];
+    const bool live = (T)0.5 * rr_new > thr && k < max_it;  // :59-62
+    if (!live) break;
+    const bool drop = rz_old <= min_float;  // :79
+    const T beta = drop ? (T)0 : rz_new / rz_old;
+    if (w == 1) pJ[l] = drop ? zv : mgp_fma(beta, pJ[l], zv);
+    else if (wq == 2 && have) pI[q][l] = drop ? zv : mgp_fma(beta, pI[q][l], zv);
+    rz_old = rz_new;
+    lds_barrier();
+    stamp(k, 2);
+    // ================================================================= tile products, epoch k + 1: lane-local only
+    const unsigned ea = (unsigned)k + 1u;
+    {
+      T cs = 0;
+      if (have) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cs = mgp_fma(a[e], pI[q][16 * wq + e], cs);  // LDS broadcast reads
+      }
+      colp[q][wq][l] = cs;
+    }
+    lds_barrier();
+    if (w == 0) {
+      T y = 0;  // the workgroup's 64-vector: groups in order, waves in order
+#pragma unroll
+      for (int g2 = 0; g2 < 4; ++g2) y += (colp[g2][0][l] + colp[g2][1][l]) + (colp[g2][2][l] + colp[g2][3][l]);
+      if (ook) Gran<T>::store(pb.Qg + (((long)J * R + rg) * TS + l + kz) * W, ea, y);
+      const T share = wave_allsum_valu(ook ? pJ[l] * y : (T)0);  // p_J . (partial of (A p)_J)
+      if (l == 0) Gran<T>::store(pb.wpg + (long)(me + kz) * W, ea, share);
+    }
+    stamp(k, 3);
+    // ================================================================= the owner's update of iteration k + 1
+    if (owner) {
+      T d = 0;
+      if (w <= 2) {
+        // wave 0: vectors 0..7 of chunk J, wave 2: vectors 8..15 (R > 8 only), wave 1: the workgroups' shares of p.Ap --
+        // all in the same round trip.  The first poll waits a little: a poll issued the moment this workgroup has
+        // published its own vector is served before the slowest producer's store has landed and costs a second one
+        T sl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp[4] = {0, 0, 0, 0};
+        const int e0 = w == 2 ? 8 : 0;
+        bool ok = w == 2 && R <= 8;
+        if (!ok)
+          for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
+        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+          bool mine = true;
+          if (w != 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e0 + e < R && ook)
+                mine = Gran<T>::load(pb.Qg + (((long)J * R + e0 + e) * TS + l + kz) * W, ea, sl[e]) && mine;
+          } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (m * 64 + l < nact) mine = Gran<T>::load(pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
+          }
+          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && l == 0) fail_s = 1;
+        if (w != 1) {
+          T ap = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ap += sl[e];  // row groups in order
+          apOwn[w >> 1][l] = ap;
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) d += tp[m];
+          d = wave_allsum_valu(d);
+          if (l == 0) sh_s[2] = d;
+        }
+      }
+      __syncthreads();
+      if (fail_s) break;
+      stamp(k, 5);
+      if (w == 0) {
+        d = sh_s[2];
+        const T gamma = (d <= min_float) ? (T)0 : rz_new / d;  // :66-68
+        const T rc = mgp_fma(-gamma, apOwn[0][l] + apOwn[1][l], rOwn[l]);  // :76
+        const T zn = JAC ? rc * dOwn[l] : rc;                   // :77
+        if (ook) Gran<T>::store(pb.zg + (oi + kz) * W, ea + 1u, zn);
+        const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
+        if (l == 0) {
+          Gran<T>::store(pb.cg + (long)(J + kz) * W, ea + 1u, prz);
+          Gran<T>::store(pb.cg + (long)(64 + J + kz) * W, ea + 1u, prr);
+          shOwn[0] = prz;
+          shOwn[1] = prr;
+        }
+        rOwn[l] = rc;
+        vOwn[l] = mgp_fma(gamma, pJ[l], vOwn[l]);  // :69
+      }
+      stamp(k, 7);
+    }
+    ++k;
+  }
+  if (w == 0 && owner && ook) {
+    v[oi] = vOwn[l];
+    r[oi] = rOwn[l];
+  }
+  if (w == 0 && owner && l == 0) {
+    cpart[J] = shOwn[0];
+    cpart[CP + J] = shOwn[1];
   }
   if (fail_s && t == 0) *pb.err = 1;
   if (me == 0 && t == 0) ctrl->iters = k;
@@ -1111,14 +1321,26 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     MGP_HIP(h, hipMalloc((void**)&trace, kTraceWords * sizeof(unsigned long long)));
     MGP_HIP(h, hipMemsetAsync(trace, 0, kTraceWords * sizeof(unsigned long long), h->stream));
   }
+  // n <= 2048 (nt <= 32): the full matrix on the chip, four tiles per workgroup (d1_persist_full_kernel)
+  const int G = (int)grid.x;
+  const int Rg = st->nt > 0 ? G / st->nt : 0;                       // row groups per chunk
+  const int rpg = Rg > 0 ? (st->nt + Rg - 1) / Rg : 99;             // tile rows per group
+  const bool full = h->cg_dense1 != 4 && st->nt <= 32 && Rg >= 1 && Rg <= 16 && rpg <= 4;
 #define MGP_D1P(TT, JV)                                                                                             \
   do {                                                                                                              \
+    if (full) {                                                                                                     \
+      hipLaunchKernelGGL((d1_persist_full_kernel<TT, JV>), grid, dim3(1024), 0, h->stream, st->ctrl, d1_pbuf<TT>(st), \
+                         (const TT*)st->A, (long)st->n, st->nt, Rg, rpg, (TT*)st->r, (TT*)st->V, (const TT*)st->dinv, \
+                         (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it, h->d1_first_poll_sleep, trace);  \
+      break;                                                                                                        \
+    }                                                                                                               \
   MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_kernel<TT, JV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)(3 * 64 * 64 * sizeof(TT))));                                                  \
   hipLaunchKernelGGL((d1_persist_kernel<TT, JV>), grid, dim3(768), 3 * 64 * 64 * sizeof(TT), h->stream, st->ctrl,     \
                      d1_pbuf<TT>(st),                                                                                \
                      (const TT*)st->A, (long)st->n, st->nt, st->ntiles, (TT*)st->r, (TT*)st->V, (const TT*)st->dinv,   \
-                     (TT*)st->cpart, (const int2*)st->tab, (TT)st->thr, (TT)st->min_float, st->max_it, trace);        \
+                     (TT*)st->cpart, (const int2*)st->tab, (TT)st->thr, (TT)st->min_float, st->max_it,               \
+                     h->d1_first_poll_sleep, trace);                                                                 \
   } while (0)
   if (st->dtype == MGP_F64) {
     if (st->dinv) MGP_D1P(double, true);

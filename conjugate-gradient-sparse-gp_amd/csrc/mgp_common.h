@@ -51,6 +51,7 @@ struct mgp_handle {
   // most right-hand sides the tile scheme takes (MGP_CG_DENSE1_COLS: 1 = one only, as round 3; up to 8); 0 = by size,
   // where it was measured faster than the skinny product + fused update: 4 for n <= 4096, 6 above
   int cg_dense1_cols = 0;
+  int d1_first_poll_sleep = 16;  // register-resident dense CG, owners: x 64 cycles before the first poll of the slots (MGP_D1_FIRST_POLL)
   bool d1_persist_off = false;  // set for the retry of a solve whose register-resident launch reported a timed-out hand-off
   int poll_pipeline = 1;  // MGP_CG_PIPELINE_POLLS=0: drain the stream at every poll (round 3)
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
