@@ -531,7 +531,10 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   // one right-hand side on a dense matrix, no residual refresh inside the solve: the two-launch iteration of
   // cg_dense1.hip (tile shares, chunk shares, two direction buffers live behind the control word)
   // ... and, since round 4, two to eight right-hand sides on the same tile scheme (the reference's default num_probes = 5)
-  const long d1_cols = h->cg_dense1_cols > 0 ? h->cg_dense1_cols : (n <= 4096 ? 4 : 6);
+  // ... up to 8 where the full matrix fits the chip (n <= 2048: the register-resident form carries the columns for 16
+  // fused multiply-adds each), else where the tile scheme was measured faster than the skinny product: 4, 6 above 4096
+  const long d1_cols = h->cg_dense1_cols > 0 ? h->cg_dense1_cols
+                       : ((!h->d1_persist_off && mgp_dense1_persist_eligible(h, n, 8)) ? 8 : (n <= 4096 ? 4 : 6));
   const bool dense1 = op->kind == MGP_OP_DENSE && Bt >= 1 && Bt <= d1_cols && !dense_pre &&
                       pc.kind != MGP_PRE_BLOCK && cycle > max_it && mgp_dense1_eligible(h, n);
   size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64 +
@@ -576,7 +579,7 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   }
   MgpDense1 d1;
   // n <= 4096: the whole solve in one launch, the upper triangle of A in registers (cg_dense1.hip)
-  const bool persist = dense1 && Bt == 1 && !h->d1_persist_off && mgp_dense1_persist_eligible(h, n);
+  const bool persist = dense1 && !h->d1_persist_off && mgp_dense1_persist_eligible(h, n, Bt);
   if (dense1) {
     MGP_TRY(mgp_dense1_begin(h, &d1, op->dtype, op->A, n, B, av, V, r,
                              pc.kind == MGP_PRE_JACOBI ? pc.diag_inv : nullptr, ctrl, d1_arena, thr, min_float, max_it,

@@ -366,7 +366,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void d1m_init_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ b,
                                                       const T* __restrict__ av, T* __restrict__ r,
                                                       const T* __restrict__ dinv, T* __restrict__ cpart,
-                                                      T* __restrict__ scal, long n, int* __restrict__ stopw) {
+                                                      T* __restrict__ scal, T* __restrict__ zpub, long n,
+                                                      int* __restrict__ stopw) {
   const int l = threadIdx.x, col = blockIdx.y;
   const long i = (long)blockIdx.x * 64 + l, off = (long)col * n;
   T rv = 0, zv = 0;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(64) void d1m_init_kernel(MgpCgCtrl* __restrict__ ct
     rv = av ? b[off + i] - av[off + i] : b[off + i];
     r[off + i] = rv;
     zv = dinv ? rv * dinv[i] : rv;
+    zpub[off + i] = zv;  // z_0 for the register-resident form
   }
   const T prz = wave_allsum(zv * rv), prr = wave_allsum(rv * rv);
   if (l == 0) {
@@ -397,9 +399,11 @@ __global__ __launch_bounds__(64) void d1m_init_kernel(MgpCgCtrl* __restrict__ ct
 
 // statistics per column + the gate for the host poll: one wave per column
 template <typename T>
-__global__ __launch_bounds__(512) void d1m_finish_kernel(MgpCgCtrl* __restrict__ ctrl, const T* __restrict__ cpart,
-                                                         T* __restrict__ rz, T* __restrict__ err,
-                                                         int* __restrict__ over, T thr, int max_it, int bt) {
+__global__ __launch_bounds__(512) void d1m_finish_kernel(MgpCgCtrl* __restrict__ ctrl,
+                                                         const int* __restrict__ hand_off_err,
+                                                         const T* __restrict__ cpart, T* __restrict__ rz,
+                                                         T* __restrict__ err, int* __restrict__ over, T thr,
+                                                         int max_it, int bt) {
   __shared__ int any_s[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   if (w < bt) {
@@ -417,7 +421,8 @@ __global__ __launch_bounds__(512) void d1m_finish_kernel(MgpCgCtrl* __restrict__
   if (threadIdx.x == 0) {
     int any = 0;
     for (int q = 0; q < bt; ++q) any |= any_s[q];
-    if (ctrl->active) ctrl->active = (any && ctrl->iters < max_it) ? 1 : 0;
+    if (*hand_off_err) ctrl->pad = 1;  // the register-resident form ran out of a poll budget
+    if (ctrl->active) ctrl->active = (any && ctrl->iters < max_it && !*hand_off_err) ? 1 : 0;
   }
 }
 
@@ -616,6 +621,8 @@ __device__ __forceinline__ void st_sc1(T* p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+using gu64 = unsigned long long;
+
 // ------------------------------------------------------------------ round 4: the matrix stays ON THE CHIP
 // For n <= 4096 the upper triangle of A (67 MB of 64 x 64 tiles at n = 4096) fits the register files of the chip
 // (256 CUs x 512 KB): one launch loads every tile ONCE -- a workgroup of 768 threads per CU (twelve waves, three per
@@ -637,36 +644,50 @@ __device__ __forceinline__ void st_sc1(T* p, T v) {
 // chunk shares: read before a workgroup publishes A), so single buffers suffice and a reader never meets a later
 // epoch.  Every wait is bounded (a poll budget, then the error word and out): a workgroup that is not resident --
 // another stream holding CUs -- makes the solve fail over to the two-launch form, never hang.
-using gu64 = unsigned long long;
 constexpr int kPersistBudget = 1 << 16;  // polls of >= 1 us each
+
+// The granule region of a solve as ONE buffer resource: a 16-byte `buffer_load/store_dwordx4 ... sc1` moves both
+// granules of an fp64 element in one instruction (8-byte atomic loads were the bound of the polls: 61 KB of them into
+// one CU per round at five columns); each 8-byte half still carries, and is checked by, its own tag.
+typedef unsigned d1_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned d1_v2u __attribute__((ext_vector_type(2)));
+struct GranRs {
+  __amdgpu_buffer_rsrc_t rs;
+  const gu64* base;
+};
+__device__ __forceinline__ GranRs make_gran_rs(const gu64* base, long bytes) {
+  GranRs g;
+  g.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+  g.base = base;
+  return g;
+}
 
 template <typename T>
 struct Gran;  // element <-> granules
 template <>
 struct Gran<double> {
   static constexpr int W = 2;  // granules per element
-  static __device__ __forceinline__ void store(gu64* g, unsigned epoch, double v) {
-    const gu64 tag = (gu64)epoch << 32;
-    __hip_atomic_store(g, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static __device__ __forceinline__ void store(const GranRs& R, gu64* g, unsigned epoch, double v) {
+    const d1_v4u x = {(unsigned)__double2loint(v), epoch, (unsigned)__double2hiint(v), epoch};
+    __builtin_amdgcn_raw_buffer_store_b128(x, R.rs, (int)((const char*)g - (const char*)R.base), 0, 16);  // aux 16 = sc1
   }
-  static __device__ __forceinline__ bool load(const gu64* g, unsigned epoch, double& v) {
-    const gu64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const gu64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
-    return (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
+  static __device__ __forceinline__ bool load(const GranRs& R, const gu64* g, unsigned epoch, double& v) {
+    const d1_v4u x = __builtin_amdgcn_raw_buffer_load_b128(R.rs, (int)((const char*)g - (const char*)R.base), 0, 16);
+    v = __hiloint2double((int)x.z, (int)x.x);
+    return x.y == epoch && x.w == epoch;
   }
 };
 template <>
 struct Gran<float> {
   static constexpr int W = 1;
-  static __device__ __forceinline__ void store(gu64* g, unsigned epoch, float v) {
-    __hip_atomic_store(g, ((gu64)epoch << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static __device__ __forceinline__ void store(const GranRs& R, gu64* g, unsigned epoch, float v) {
+    const d1_v2u x = {(unsigned)__float_as_int(v), epoch};
+    __builtin_amdgcn_raw_buffer_store_b64(x, R.rs, (int)((const char*)g - (const char*)R.base), 0, 16);
   }
-  static __device__ __forceinline__ bool load(const gu64* g, unsigned epoch, float& v) {
-    const gu64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v = __int_as_float((int)(unsigned)a);
-    return (unsigned)(a >> 32) == epoch;
+  static __device__ __forceinline__ bool load(const GranRs& R, const gu64* g, unsigned epoch, float& v) {
+    const d1_v2u x = __builtin_amdgcn_raw_buffer_load_b64(R.rs, (int)((const char*)g - (const char*)R.base), 0, 16);
+    v = __int_as_float((int)x.x);
+    return x.y == epoch;
   }
 };
 
@@ -677,6 +698,7 @@ struct D1PBuf {
   gu64* cg;    // [2][64] elements: the chunks' shares of rz and of ||r||^2
   gu64* zg;    // [n] elements: z = M^-1 r
   int* err;
+  long bytes;  // of the whole granule region, which begins at Qg
 };
 
 // epoch-1 granules of the initial residual (d1_init_kernel left z_0 in zpub and the shares in cpart)
@@ -684,12 +706,14 @@ template <typename T>
 __global__ __launch_bounds__(64) void d1_persist_seed_kernel(const T* __restrict__ zpub, const T* __restrict__ cpart,
                                                              D1PBuf pb, long n, int nt) {
   constexpr int W = Gran<T>::W;
-  const int l = threadIdx.x;
+  const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
+  const int l = threadIdx.x, col = blockIdx.y;
   const long i = (long)blockIdx.x * 64 + l;
-  if (i < n) Gran<T>::store(pb.zg + i * W, 1u, zpub[i]);
+  if (i < n) Gran<T>::store(grs, pb.zg + ((long)col * n + i) * W, 1u, zpub[(long)col * n + i]);
   if (blockIdx.x == 0 && l < nt) {
-    Gran<T>::store(pb.cg + (long)l * W, 1u, cpart[l]);
-    Gran<T>::store(pb.cg + (long)(64 + l) * W, 1u, cpart[CP + l]);
+    const T* cp = cpart + (long)col * 2 * CP;
+    Gran<T>::store(grs, pb.cg + ((long)col * 128 + l) * W, 1u, cp[l]);
+    Gran<T>::store(grs, pb.cg + ((long)col * 128 + 64 + l) * W, 1u, cp[CP + l]);
   }
 }
 
@@ -702,6 +726,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
                                                          int first_poll_sleep, unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
+  const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..11: twelve waves, three per SIMD, up to 168 VGPRs each
   // diagnosis (MGP_D1_TRACE=<file>): thread 0 of workgroups 0 (owner of chunk 0) and 1 (no chunk) stamps the 100 MHz
@@ -792,17 +817,17 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
       for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
         bool mine = true;
         if (w == 0 && l < nt) {
-          mine = Gran<T>::load(pb.cg + (long)(l + kz) * W, eb, z0) && mine;
-          mine = Gran<T>::load(pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
+          mine = Gran<T>::load(grs, pb.cg + (long)(l + kz) * W, eb, z0) && mine;
+          mine = Gran<T>::load(grs, pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
         }
 #pragma unroll
         for (int ly = 0; ly < 3; ++ly) {
           if (tI[ly] >= 0 && wq < 2) {
             const long e = (long)(wq == 0 ? tJ[ly] : tI[ly]) * TS + l + kz;
-            if (e < n) mine = Gran<T>::load(pb.zg + e * W, eb, zj[ly]) && mine;
+            if (e < n) mine = Gran<T>::load(grs, pb.zg + e * W, eb, zj[ly]) && mine;
           }
         }
-        if (w == 11 && ook) mine = Gran<T>::load(pb.zg + (oi + kz) * W, eb, zo) && mine;
+        if (w == 11 && ook) mine = Gran<T>::load(grs, pb.zg + (oi + kz) * W, eb, zo) && mine;
         ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
         if (!ok) __builtin_amdgcn_s_sleep(2);
       }
@@ -868,7 +893,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
         sr += lane_xor_row<2>(sr);
         sr += lane_xor_row<1>(sr);  // lane l: (A_IJ p_J)[16 wq + (l >> 2)]
         const long i = (long)I * TS + 16 * wq + (l >> 2) + kz;
-        if ((l & 3) == 0 && i < n) Gran<T>::store(pb.Qg + ((long)J * n + i) * W, ea, sr);
+        if ((l & 3) == 0 && i < n) Gran<T>::store(grs, pb.Qg + ((long)J * n + i) * W, ea, sr);
         const T prow = pI[s][16 * wq + (l >> 2)];
         const T u = wave_allsum_valu((l & 3) == 0 ? sr * prow : (T)0);
         if (l == 0) gsum[ly][g][wq] = u;
@@ -883,7 +908,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
         if (wq == ly && I != J) {  // the column sums of layer ly by wave ly of the group: three waves share the three layers
           const T sc = (colp[ly][g][0][l] + colp[ly][g][1][l]) + (colp[ly][g][2][l] + colp[ly][g][3][l]);
           const long ic2 = (long)J * TS + l + kz;
-          if (ic2 < n) Gran<T>::store(pb.Qg + ((long)I * n + ic2) * W, ea, sc);
+          if (ic2 < n) Gran<T>::store(grs, pb.Qg + ((long)I * n + ic2) * W, ea, sc);
         }
         const T tot = (gsum[ly][g][0] + gsum[ly][g][1]) + (gsum[ly][g][2] + gsum[ly][g][3]);
         share += I == J ? tot : tot + tot;  // the same in the four waves of the group
@@ -893,7 +918,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
     // the workgroup's share of p.Ap: per group its layers in order, then the groups in order
     if (wq == 0 && l == 0) gsum[0][g][0] = share;
     lds_barrier();
-    if (t == 0) Gran<T>::store(pb.wpg + (long)(me + kz) * W, ea, (gsum[0][0][0] + gsum[0][1][0]) + gsum[0][2][0]);
+    if (t == 0) Gran<T>::store(grs, pb.wpg + (long)(me + kz) * W, ea, (gsum[0][0][0] + gsum[0][1][0]) + gsum[0][2][0]);
     stamp(k, 3);
     // ================================================================= the owner's update of iteration k + 1
     if (own >= 0) {
@@ -910,7 +935,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
           bool mine = true;
 #pragma unroll
           for (int m = 0; m < 4; ++m)
-            if (m * 64 + l < G) mine = Gran<T>::load(pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
+            if (m * 64 + l < G) mine = Gran<T>::load(grs, pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
           ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
           if (!ok) __builtin_amdgcn_s_sleep(2);
         }
@@ -932,7 +957,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
 #pragma unroll
           for (int q = 0; q < 6; ++q)
             if (6 * w + q < nt && oi < n)
-              mine = Gran<T>::load(pb.Qg + ((long)(6 * w + q) * n + oi + kz) * W, ea, sl[q]) && mine;
+              mine = Gran<T>::load(grs, pb.Qg + ((long)(6 * w + q) * n + oi + kz) * W, ea, sl[q]) && mine;
           ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
           if (!ok) __builtin_amdgcn_s_sleep(2);
         }
@@ -954,11 +979,11 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
         for (int q = 1; q < 12; ++q) ap += part[q][l];
         const T rc = mgp_fma(-gamma, ap, rOwn[l]);  // :76
         const T zn = JAC ? rc * dOwn[l] : rc;       // :77
-        if (ook) Gran<T>::store(pb.zg + (oi + kz) * W, ea + 1u, zn);  // first: the critical path of everybody else
+        if (ook) Gran<T>::store(grs, pb.zg + (oi + kz) * W, ea + 1u, zn);  // first: the critical path of everybody else
         const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
         if (l == 0) {
-          Gran<T>::store(pb.cg + (long)(own + kz) * W, ea + 1u, prz);
-          Gran<T>::store(pb.cg + (long)(64 + own + kz) * W, ea + 1u, prr);
+          Gran<T>::store(grs, pb.cg + (long)(own + kz) * W, ea + 1u, prz);
+          Gran<T>::store(grs, pb.cg + (long)(64 + own + kz) * W, ea + 1u, prr);
           shOwn[0] = prz;
           shOwn[1] = prr;
         }
@@ -987,10 +1012,14 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
 // column set removes the expensive half of the triangle scheme: workgroup (J, rg) holds the tiles (I, J) of its row
 // group rg (up to four tile rows I, one per four-wave group) and forms ONLY the lane-local product
 //     y_J[c] += sum_r A[I rows r][c] * p_I[r]     (= (A_JI p_I)[c] by symmetry: lane = column, no cross-lane step),
-// sums its four tiles in LDS and publishes ONE 64-vector per workgroup -- a chunk's (A p)_J is the sum of R = G / nt
-// such vectors (8 at nt = 32, against 32 slots in the triangle scheme), and the owner of chunk J polls them and the
-// workgroups' shares of p.Ap in the SAME round trip.  Hand-offs, epochs, bounds and fail-over as in d1_persist_kernel.
-template <typename T, bool JAC>
+// sums its four tiles in LDS and publishes ONE 64-vector per workgroup and column -- a chunk's (A p)_J is the sum of
+// R = G / nt such vectors (8 at nt = 32, against 32 slots in the triangle scheme), and the owner of chunk J polls them
+// and the workgroups' shares of p.Ap in the SAME round trip.  With no cross-lane work a further right-hand side costs
+// 16 fused multiply-adds per tile and wave, so the form carries BT <= 8 columns (the reference's default of 5 probes,
+// models.py:286, at C2's M = 2048): per column its own recurrence (:64-85) and guards (:68, :79), `any` over the
+// columns as stopping rule (:59-62).  Hand-offs, epochs, bounds and fail-over as in d1_persist_kernel.  Granule arrays
+// per column e: cg + e 128 W, zg + e n W, wpg + e 256 W, Qg + e (nt R 64) W.
+template <typename T, bool JAC, int BT>
 __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
                                                               const T* __restrict__ A, long n, int nt, int R, int rpg,
                                                               T* __restrict__ r, T* __restrict__ v,
@@ -999,6 +1028,7 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
                                                               unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
+  const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..15
   const int q = w >> 2, wq = w & 3;                       // four-wave group = tile of the workgroup, wave in the group
@@ -1013,10 +1043,13 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
   const int I = rg * rpg + q;               // tile row of this group
   const bool have = q < rpg && I < nt;      // uniform per group
   const bool owner = rg == 0;               // of chunk J
-  __shared__ T pJ[TS], pI[4][TS];
-  __shared__ T colp[4][4][TS];
-  __shared__ T rOwn[TS], vOwn[TS], dOwn[TS], shOwn[2], apOwn[2][TS];
-  __shared__ T sh_s[3];
+  const long qstride = (long)nt * R * TS;   // elements of one column's vectors
+  __shared__ T pJ[BT][TS], pI[4][BT][TS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char d1f_dyn_lds[];  // colp[BT][4][4][TS]: 8 KB per column in fp64
+  T(*colp)[4][4][TS] = reinterpret_cast<T(*)[4][4][TS]>(d1f_dyn_lds);
+  __shared__ T rOwn[BT][TS], vOwn[BT][TS], dOwn[TS], shOwn[BT][2], apOwn[BT][TS];
+  __shared__ T sh_s[BT][3];   // per column: rz, ||r||^2 of the current residual, p.Ap
+  __shared__ T rzo_s[BT];     // per column: rz of the previous iteration (LDS, not BT registers in every thread)
   __shared__ int fail_s;
   if (t == 0) fail_s = 0;
   // ---- the group's tile, once: rows 16 wq .. 16 wq + 15 of tile (I, J), lane = column; ragged edges are zeros
@@ -1033,16 +1066,19 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
   }
   const long oi = (long)J * TS + l;  // element of chunk J
   const bool ook = oi < n;
-  if (w == 0 && owner) {
-    rOwn[l] = ook ? r[oi] : (T)0;
-    vOwn[l] = ook ? v[oi] : (T)0;
-    dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
+  if (owner && w < BT) {  // wave e: column e of the owner's chunk
+    rOwn[w][l] = ook ? r[(long)w * n + oi] : (T)0;
+    vOwn[w][l] = ook ? v[(long)w * n + oi] : (T)0;
+    if (w == 0) dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
     if (l == 0) {
-      shOwn[0] = cpart[J];
-      shOwn[1] = cpart[CP + J];
+      shOwn[w][0] = cpart[(long)w * 2 * CP + J];
+      shOwn[w][1] = cpart[(long)w * 2 * CP + CP + J];
     }
   }
-  T rz_old = 0;
+  // duties of the B phase, spread over the sixteen waves: duty d < BT: the shares of column d; BT <= d < 2 BT: z of
+  // chunk J, column d - BT (-> p_J); 2 BT <= d < 6 BT: z of tile row I_g, column e (-> p_I[g]), d = 2 BT + 4 e + g
+  constexpr int ND = 6 * BT, DPW = (ND + 15) / 16;  // duties per wave
+  if (t < BT) rzo_s[t] = 0;  // 0 makes p_1 = z_0 (the beta-term dropped, :79-84)
   int k = 0;
   __syncthreads();
   while (true) {
@@ -1051,139 +1087,161 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
     stamp(k, 0);
     // ================================================================= B_k
     const unsigned eb = (unsigned)k + 1u;
-    T zv = 0;  // wave (q, 0): z of the group's tile row I; wave 1: z of chunk J
+    T dv[DPW][2];  // a duty's values: shares -> (rz share, rr share); z -> (z, -)
     {
-      const bool duty = w == 0 || w == 1 || (wq == 2 && have);
-      T z0 = 0, q0 = 0;
-      bool ok = !duty;
+      bool ok = false;
       for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
         bool mine = true;
-        if (w == 0) {
-          if (l < nt) {
-            mine = Gran<T>::load(pb.cg + (long)(l + kz) * W, eb, z0) && mine;
-            mine = Gran<T>::load(pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
+#pragma unroll
+        for (int s = 0; s < DPW; ++s) {
+          const int d = w + 16 * s;
+          dv[s][0] = dv[s][1] = 0;
+          if (d < BT) {
+            if (l < nt) {
+              mine = Gran<T>::load(grs, pb.cg + ((long)d * 128 + l + kz) * W, eb, dv[s][0]) && mine;
+              mine = Gran<T>::load(grs, pb.cg + ((long)d * 128 + 64 + l + kz) * W, eb, dv[s][1]) && mine;
+            }
+          } else if (d < 2 * BT) {
+            if (ook) mine = Gran<T>::load(grs, pb.zg + ((long)(d - BT) * n + oi + kz) * W, eb, dv[s][0]) && mine;
+          } else if (d < ND) {
+            const int e = (d - 2 * BT) >> 2, g2 = (d - 2 * BT) & 3;
+            const int I2 = rg * rpg + g2;
+            const long el = (long)I2 * TS + l + kz;
+            if (g2 < rpg && I2 < nt && el < n) mine = Gran<T>::load(grs, pb.zg + ((long)e * n + el) * W, eb, dv[s][0]) && mine;
           }
-        } else if (w == 1) {
-          if (ook) mine = Gran<T>::load(pb.zg + (oi + kz) * W, eb, zv) && mine;
-        } else {
-          const long e = (long)I * TS + l + kz;
-          if (e < n) mine = Gran<T>::load(pb.zg + e * W, eb, zv) && mine;
         }
         ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
         if (!ok) __builtin_amdgcn_s_sleep(2);
       }
       if (!ok && l == 0) fail_s = 1;
-      if (w == 0) {
-        const T a_rz = wave_allsum_valu(z0), a_rr = wave_allsum_valu(q0);
-        if (l == 0) {
-          sh_s[0] = a_rz;
-          sh_s[1] = a_rr;
+#pragma unroll
+      for (int s = 0; s < DPW; ++s) {
+        const int d = w + 16 * s;
+        if (d < BT) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
+          const T a_rz = wave_allsum_valu(dv[s][0]), a_rr = wave_allsum_valu(dv[s][1]);
+          if (l == 0) {
+            sh_s[d][0] = a_rz;
+            sh_s[d][1] = a_rr;
+          }
         }
       }
     }
     __syncthreads();
     stamp(k, 1);
     if (fail_s) break;
-    const T rz_new = sh_s[0], rr_new = sh_s[1];
-    const bool live = (T)0.5 * rr_new > thr && k < max_it;  // :59-62
-    if (!live) break;
-    const bool drop = rz_old <= min_float;  // :79
-    const T beta = drop ? (T)0 : rz_new / rz_old;
-    if (w == 1) pJ[l] = drop ? zv : mgp_fma(beta, pJ[l], zv);
-    else if (wq == 2 && have) pI[q][l] = drop ? zv : mgp_fma(beta, pI[q][l], zv);
-    rz_old = rz_new;
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < BT; ++e) any = any || (T)0.5 * sh_s[e][1] > thr;
+    if (!(any && k < max_it)) break;  // :59-62
+#pragma unroll
+    for (int s = 0; s < DPW; ++s) {
+      const int d = w + 16 * s;
+      if (d >= BT && d < ND) {
+        const int e = d < 2 * BT ? d - BT : (d - 2 * BT) >> 2;
+        T* dst = d < 2 * BT ? pJ[e] : pI[(d - 2 * BT) & 3][e];
+        const T ro = rzo_s[e], rn = sh_s[e][0];
+        const bool drop = ro <= min_float;  // :79, per column
+        const T beta = drop ? (T)0 : rn / ro;
+        dst[l] = drop ? dv[s][0] : mgp_fma(beta, dst[l], dv[s][0]);  // a select, not 0 * p
+      }
+    }
     lds_barrier();
+    if (t < BT) rzo_s[t] = sh_s[t][0];  // read again only after the next B phase's barrier
     stamp(k, 2);
     // ================================================================= tile products, epoch k + 1: lane-local only
     const unsigned ea = (unsigned)k + 1u;
-    {
+#pragma unroll
+    for (int e = 0; e < BT; ++e) {
       T cs = 0;
       if (have) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cs = mgp_fma(a[e], pI[q][16 * wq + e], cs);  // LDS broadcast reads
+        for (int i2 = 0; i2 < 16; ++i2) cs = mgp_fma(a[i2], pI[q][e][16 * wq + i2], cs);  // LDS broadcast reads
       }
-      colp[q][wq][l] = cs;
+      colp[e][q][wq][l] = cs;
     }
     lds_barrier();
-    if (w == 0) {
-      T y = 0;  // the workgroup's 64-vector: groups in order, waves in order
+    if (w < BT) {  // wave e: column e -- the workgroup's 64-vector: groups in order, waves in order
+      T y = 0;
 #pragma unroll
-      for (int g2 = 0; g2 < 4; ++g2) y += (colp[g2][0][l] + colp[g2][1][l]) + (colp[g2][2][l] + colp[g2][3][l]);
-      if (ook) Gran<T>::store(pb.Qg + (((long)J * R + rg) * TS + l + kz) * W, ea, y);
-      const T share = wave_allsum_valu(ook ? pJ[l] * y : (T)0);  // p_J . (partial of (A p)_J)
-      if (l == 0) Gran<T>::store(pb.wpg + (long)(me + kz) * W, ea, share);
+      for (int g2 = 0; g2 < 4; ++g2)
+        y += (colp[w][g2][0][l] + colp[w][g2][1][l]) + (colp[w][g2][2][l] + colp[w][g2][3][l]);
+      if (ook) Gran<T>::store(grs, pb.Qg + ((long)w * qstride + ((long)J * R + rg) * TS + l + kz) * W, ea, y);
+      const T share = wave_allsum_valu(ook ? pJ[w][l] * y : (T)0);  // p_J . (partial of (A p)_J)
+      if (l == 0) Gran<T>::store(grs, pb.wpg + ((long)w * 256 + me + kz) * W, ea, share);
     }
     stamp(k, 3);
     // ================================================================= the owner's update of iteration k + 1
     if (owner) {
-      T d = 0;
-      if (w <= 2) {
-        // wave 0: vectors 0..7 of chunk J, wave 2: vectors 8..15 (R > 8 only), wave 1: the workgroups' shares of p.Ap --
-        // all in the same round trip.  The first poll waits a little: a poll issued the moment this workgroup has
-        // published its own vector is served before the slowest producer's store has landed and costs a second one
+      // wave 2 e: the R <= 8 vectors of chunk J, column e; wave 2 e + 1: the workgroups' shares of p.Ap, column e -- all
+      // in the same round trip.  The first poll waits a little: one issued the moment this workgroup has published its
+      // own vector is served before the slowest producer's store has landed and costs a second round trip
+      if (w < 2 * BT) {
+        const int e = w >> 1;
         T sl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp[4] = {0, 0, 0, 0};
-        const int e0 = w == 2 ? 8 : 0;
-        bool ok = w == 2 && R <= 8;
-        if (!ok)
-          for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
+        bool ok = false;
+        for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
         for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
           bool mine = true;
-          if (w != 1) {
+          if ((w & 1) == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (e0 + e < R && ook)
-                mine = Gran<T>::load(pb.Qg + (((long)J * R + e0 + e) * TS + l + kz) * W, ea, sl[e]) && mine;
+            for (int i2 = 0; i2 < 8; ++i2)
+              if (i2 < R && ook)
+                mine = Gran<T>::load(grs, pb.Qg + ((long)e * qstride + ((long)J * R + i2) * TS + l + kz) * W, ea, sl[i2]) && mine;
           } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-              if (m * 64 + l < nact) mine = Gran<T>::load(pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
+              if (m * 64 + l < nact)
+                mine = Gran<T>::load(grs, pb.wpg + ((long)e * 256 + m * 64 + l + kz) * W, ea, tp[m]) && mine;
           }
           ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
           if (!ok) __builtin_amdgcn_s_sleep(2);
         }
         if (!ok && l == 0) fail_s = 1;
-        if (w != 1) {
+        if ((w & 1) == 0) {
           T ap = 0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ap += sl[e];  // row groups in order
-          apOwn[w >> 1][l] = ap;
+          for (int i2 = 0; i2 < 8; ++i2) ap += sl[i2];  // row groups in order
+          apOwn[e][l] = ap;
         } else {
+          T d = 0;
 #pragma unroll
           for (int m = 0; m < 4; ++m) d += tp[m];
           d = wave_allsum_valu(d);
-          if (l == 0) sh_s[2] = d;
+          if (l == 0) sh_s[e][2] = d;
         }
       }
       __syncthreads();
       if (fail_s) break;
       stamp(k, 5);
-      if (w == 0) {
-        d = sh_s[2];
-        const T gamma = (d <= min_float) ? (T)0 : rz_new / d;  // :66-68
-        const T rc = mgp_fma(-gamma, apOwn[0][l] + apOwn[1][l], rOwn[l]);  // :76
+      if (w < BT) {  // wave e: column e
+        const T d = sh_s[w][2];
+        const T gamma = (d <= min_float) ? (T)0 : sh_s[w][0] / d;  // :66-68 (rz of the residual the direction came from)
+        const T rc = mgp_fma(-gamma, apOwn[w][l], rOwn[w][l]);  // :76
         const T zn = JAC ? rc * dOwn[l] : rc;                   // :77
-        if (ook) Gran<T>::store(pb.zg + (oi + kz) * W, ea + 1u, zn);
+        if (ook) Gran<T>::store(grs, pb.zg + ((long)w * n + oi + kz) * W, ea + 1u, zn);
         const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
         if (l == 0) {
-          Gran<T>::store(pb.cg + (long)(J + kz) * W, ea + 1u, prz);
-          Gran<T>::store(pb.cg + (long)(64 + J + kz) * W, ea + 1u, prr);
-          shOwn[0] = prz;
-          shOwn[1] = prr;
+          Gran<T>::store(grs, pb.cg + ((long)w * 128 + J + kz) * W, ea + 1u, prz);
+          Gran<T>::store(grs, pb.cg + ((long)w * 128 + 64 + J + kz) * W, ea + 1u, prr);
+          shOwn[w][0] = prz;
+          shOwn[w][1] = prr;
         }
-        rOwn[l] = rc;
-        vOwn[l] = mgp_fma(gamma, pJ[l], vOwn[l]);  // :69
+        rOwn[w][l] = rc;
+        vOwn[w][l] = mgp_fma(gamma, pJ[w][l], vOwn[w][l]);  // :69
       }
       stamp(k, 7);
     }
     ++k;
   }
-  if (w == 0 && owner && ook) {
-    v[oi] = vOwn[l];
-    r[oi] = rOwn[l];
-  }
-  if (w == 0 && owner && l == 0) {
-    cpart[J] = shOwn[0];
-    cpart[CP + J] = shOwn[1];
+  if (owner && w < BT) {
+    if (ook) {
+      v[(long)w * n + oi] = vOwn[w][l];
+      r[(long)w * n + oi] = rOwn[w][l];
+    }
+    if (l == 0) {
+      cpart[(long)w * 2 * CP + J] = shOwn[w][0];
+      cpart[(long)w * 2 * CP + CP + J] = shOwn[w][1];
+    }
   }
   if (fail_s && t == 0) *pb.err = 1;
   if (me == 0 && t == 0) ctrl->iters = k;
@@ -1206,7 +1264,7 @@ int d1_layout(MgpDense1* st, void* arena, long n) {
   st->pb[1] = a + bt * n;
   a += 2 * bt * n;
   st->zpub = a;
-  a += n;
+  a += bt * n;
   st->Qm = nullptr;
   if (bt > 1) {
     st->Qm = a;
@@ -1217,18 +1275,20 @@ int d1_layout(MgpDense1* st, void* arena, long n) {
   return MGP_OK;
 }
 
-static size_t d1_gran_bytes(int dtype, long n) {
+// granule elements: Qg (triangle form: nt n; full form: bt nt 8 64 <= bt nt n / 8) | wpg bt 256 | cg bt 128 | zg bt n
+static size_t d1_gran_bytes(int dtype, long n, long bt) {
   const long nt = (n + 63) / 64;
-  return (size_t)(nt * n + 256 + 128 + n) * (dtype == MGP_F64 ? 2 : 1) * sizeof(gu64);
+  const long qg = nt * n > bt * nt * 8 * 64 ? nt * n : bt * nt * 8 * 64;
+  return (size_t)(qg + bt * (256 + 128 + n)) * (dtype == MGP_F64 ? 2 : 1) * sizeof(gu64);
 }
 
 }  // namespace
 
 size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n, int64_t bt) {
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
-  size_t e = (size_t)(bt * (ntiles + 2 * CP + 2 + 2 * n) + n);
+  size_t e = (size_t)(bt * (ntiles + 2 * CP + 2 + 3 * n));
   if (bt > 1) e += (size_t)bt * nt * n;
-  return e * mgp_elem(dtype) + 128 + 128 + ((bt == 1 && mgp_dense1_persist_eligible(h, n)) ? d1_gran_bytes(dtype, n) : 0) + 64;
+  return e * mgp_elem(dtype) + 128 + 128 + (mgp_dense1_persist_eligible(h, n, bt) ? d1_gran_bytes(dtype, n, bt) : 0) + 64;
 }
 
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n) {
@@ -1237,10 +1297,26 @@ bool mgp_dense1_eligible(const mgp_handle* h, int64_t n) {
 
 // the register-resident form: every tile on the chip at once -- at most nine per workgroup, one workgroup per CU
 static int d1_persist_grid(const mgp_handle* h) { return h->num_cus < 256 ? h->num_cus : 256; }
-bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n) {
+// full-matrix form (d1_persist_full_kernel): nt <= 32 tile rows, R = min(8, G / nt) row groups of <= 4 tile rows
+static bool d1_full_geometry(const mgp_handle* h, long nt, int* R, int* rpg) {
+  const int G = d1_persist_grid(h);
+  int r = nt > 0 ? (int)(G / nt) : 0;
+  if (r > 8) r = 8;
+  if (r < 1 || nt > 32) return false;
+  const int g = (int)((nt + r - 1) / r);
+  if (g > 4) return false;
+  *R = r;
+  *rpg = g;
+  return true;
+}
+bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n, int64_t bt) {
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
   const int G = d1_persist_grid(h);
-  return h->cg_dense1 >= 3 && mgp_dense1_eligible(h, n) && nt <= 64 && nt <= G && ntiles <= 9L * G;
+  if (h->cg_dense1 < 3 || !mgp_dense1_eligible(h, n) || bt < 1 || bt > 8) return false;
+  int R = 0, rpg = 0;
+  const bool full = h->cg_dense1 != 4 && d1_full_geometry(h, nt, &R, &rpg);
+  if (bt > 1) return full;  // several columns: the full-matrix form only (no cross-lane work per column)
+  return full || (nt <= 64 && nt <= G && ntiles <= 9L * G);
 }
 
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
@@ -1264,18 +1340,18 @@ int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int
   else d1_layout<float>(st, arena, n);
   MGP_HIP(h, hipMemsetAsync(st->cpart, 0, (size_t)bt * 2 * CP * mgp_elem(dtype), h->stream));  // shares of chunks beyond nt stay 0
   // the hand-off error word and -- a tag left by an earlier solve must never match an epoch of this one -- every granule
-  MGP_HIP(h, hipMemsetAsync(st->sync, 0, 128 + (persist ? d1_gran_bytes(dtype, n) : 0), h->stream));
+  MGP_HIP(h, hipMemsetAsync(st->sync, 0, 128 + (persist ? d1_gran_bytes(dtype, n, bt) : 0), h->stream));
   // the product's slots and the tile table (dense.hip owns both)
   MGP_TRY(mgp_symm_gemv_tri_prepare(h, dtype, n, &st->Q, &st->tab));
   if (bt > 1) {
     const dim3 g((unsigned)st->nt, (unsigned)bt);
     if (dtype == MGP_F64)
       hipLaunchKernelGGL((d1m_init_kernel<double>), g, dim3(64), 0, h->stream, ctrl, (const double*)B, (const double*)av,
-                         (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal, (long)n,
-                         (int*)st->sync + 1);
+                         (double*)r, (const double*)dinv, (double*)st->cpart, (double*)st->scal, (double*)st->zpub,
+                         (long)n, (int*)st->sync + 1);
     else
       hipLaunchKernelGGL((d1m_init_kernel<float>), g, dim3(64), 0, h->stream, ctrl, (const float*)B, (const float*)av,
-                         (float*)r, (const float*)dinv, (float*)st->cpart, (float*)st->scal, (long)n,
+                         (float*)r, (const float*)dinv, (float*)st->cpart, (float*)st->scal, (float*)st->zpub, (long)n,
                          (int*)st->sync + 1);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;
@@ -1296,23 +1372,26 @@ template <typename T>
 static D1PBuf d1_pbuf(const MgpDense1* st) {
   constexpr long W = Gran<T>::W;
   D1PBuf pb;
+  const long bt = st->bt, qtri = (long)st->nt * st->n, qfull = bt * st->nt * 8 * 64;
   pb.Qg = (gu64*)st->gran;
-  pb.wpg = pb.Qg + (long)st->nt * st->n * W;
-  pb.cg = pb.wpg + 256 * W;
-  pb.zg = pb.cg + 128 * W;
+  pb.wpg = pb.Qg + (qtri > qfull ? qtri : qfull) * W;
+  pb.cg = pb.wpg + bt * 256 * W;
+  pb.zg = pb.cg + bt * 128 * W;
   pb.err = (int*)st->sync;
+  pb.bytes = (long)d1_gran_bytes(st->dtype, (long)st->n, bt);
   return pb;
 }
 
 // the whole solve in one launch (after begin + finish have left the statistics of r_0 and the first gate)
 int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
   const dim3 grid((unsigned)d1_persist_grid(h));
+  const dim3 sgrid((unsigned)st->nt, (unsigned)st->bt);
   if (st->dtype == MGP_F64)
-    hipLaunchKernelGGL((d1_persist_seed_kernel<double>), dim3((unsigned)st->nt), dim3(64), 0, h->stream,
-                       (const double*)st->zpub, (const double*)st->cpart, d1_pbuf<double>(st), (long)st->n, st->nt);
+    hipLaunchKernelGGL((d1_persist_seed_kernel<double>), sgrid, dim3(64), 0, h->stream, (const double*)st->zpub,
+                       (const double*)st->cpart, d1_pbuf<double>(st), (long)st->n, st->nt);
   else
-    hipLaunchKernelGGL((d1_persist_seed_kernel<float>), dim3((unsigned)st->nt), dim3(64), 0, h->stream,
-                       (const float*)st->zpub, (const float*)st->cpart, d1_pbuf<float>(st), (long)st->n, st->nt);
+    hipLaunchKernelGGL((d1_persist_seed_kernel<float>), sgrid, dim3(64), 0, h->stream, (const float*)st->zpub,
+                       (const float*)st->cpart, d1_pbuf<float>(st), (long)st->n, st->nt);
   MGP_LAUNCH_CHECK(h);
   unsigned long long* trace = nullptr;
   const char* trace_path = getenv("MGP_D1_TRACE");
@@ -1321,17 +1400,35 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     MGP_HIP(h, hipMalloc((void**)&trace, kTraceWords * sizeof(unsigned long long)));
     MGP_HIP(h, hipMemsetAsync(trace, 0, kTraceWords * sizeof(unsigned long long), h->stream));
   }
-  // n <= 2048 (nt <= 32): the full matrix on the chip, four tiles per workgroup (d1_persist_full_kernel)
-  const int G = (int)grid.x;
-  const int Rg = st->nt > 0 ? G / st->nt : 0;                       // row groups per chunk
-  const int rpg = Rg > 0 ? (st->nt + Rg - 1) / Rg : 99;             // tile rows per group
-  const bool full = h->cg_dense1 != 4 && st->nt <= 32 && Rg >= 1 && Rg <= 16 && rpg <= 4;
+  // n <= 2048 (nt <= 32): the full matrix on the chip, four tiles per workgroup (d1_persist_full_kernel, 1..8 columns)
+  int Rg = 0, rpg = 0;
+  const bool full = h->cg_dense1 != 4 && d1_full_geometry(h, st->nt, &Rg, &rpg);
+  if (st->bt > 1 && !full) return mgp_fail(h, MGP_E_BADARG, "dense CG: several columns need the full-matrix form");
+#define MGP_D1F(TT, JV, BTV)                                                                                         \
+  do {                                                                                                               \
+    const size_t dyn = (size_t)BTV * 16 * 64 * sizeof(TT);                                                           \
+    MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_full_kernel<TT, JV, BTV>,                                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                           \
+    hipLaunchKernelGGL((d1_persist_full_kernel<TT, JV, BTV>), grid, dim3(1024), dyn, h->stream, st->ctrl,              \
+                       d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Rg, rpg, (TT*)st->r, (TT*)st->V,       \
+                       (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
+                       h->d1_first_poll_sleep, trace);                                                               \
+  } while (0)
+#define MGP_D1FB(TT, JV)                     \
+  switch (st->bt) {                          \
+    case 1: MGP_D1F(TT, JV, 1); break;       \
+    case 2: MGP_D1F(TT, JV, 2); break;       \
+    case 3: MGP_D1F(TT, JV, 3); break;       \
+    case 4: MGP_D1F(TT, JV, 4); break;       \
+    case 5: MGP_D1F(TT, JV, 5); break;       \
+    case 6: MGP_D1F(TT, JV, 6); break;       \
+    case 7: MGP_D1F(TT, JV, 7); break;       \
+    default: MGP_D1F(TT, JV, 8); break;      \
+  }
 #define MGP_D1P(TT, JV)                                                                                             \
   do {                                                                                                              \
     if (full) {                                                                                                     \
-      hipLaunchKernelGGL((d1_persist_full_kernel<TT, JV>), grid, dim3(1024), 0, h->stream, st->ctrl, d1_pbuf<TT>(st), \
-                         (const TT*)st->A, (long)st->n, st->nt, Rg, rpg, (TT*)st->r, (TT*)st->V, (const TT*)st->dinv, \
-                         (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it, h->d1_first_poll_sleep, trace);  \
+      MGP_D1FB(TT, JV);                                                                                             \
       break;                                                                                                        \
     }                                                                                                               \
   MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_kernel<TT, JV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1349,6 +1446,8 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     if (st->dinv) MGP_D1P(float, true);
     else MGP_D1P(float, false);
   }
+#undef MGP_D1F
+#undef MGP_D1FB
 #undef MGP_D1P
   MGP_LAUNCH_CHECK(h);
   if (trace) {  // diagnosis only: drains the stream
@@ -1450,10 +1549,10 @@ int mgp_dense1_step(mgp_handle* h, const MgpDense1* st, int64_t k) {
 int mgp_dense1_finish(mgp_handle* h, MgpDense1* st, void* rz, void* err, int* over) {
   if (st->bt > 1) {
     if (st->dtype == MGP_F64)
-      hipLaunchKernelGGL((d1m_finish_kernel<double>), dim3(1), dim3(512), 0, h->stream, st->ctrl,
+      hipLaunchKernelGGL((d1m_finish_kernel<double>), dim3(1), dim3(512), 0, h->stream, st->ctrl, (const int*)st->sync,
                          (const double*)st->cpart, (double*)rz, (double*)err, over, (double)st->thr, st->max_it, st->bt);
     else
-      hipLaunchKernelGGL((d1m_finish_kernel<float>), dim3(1), dim3(512), 0, h->stream, st->ctrl,
+      hipLaunchKernelGGL((d1m_finish_kernel<float>), dim3(1), dim3(512), 0, h->stream, st->ctrl, (const int*)st->sync,
                          (const float*)st->cpart, (float*)rz, (float*)err, over, (float)st->thr, st->max_it, st->bt);
     MGP_LAUNCH_CHECK(h);
     return MGP_OK;

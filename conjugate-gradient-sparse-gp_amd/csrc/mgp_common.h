@@ -272,7 +272,7 @@ struct MgpDense1 {
 };
 size_t mgp_dense1_bytes(const mgp_handle* h, int dtype, int64_t n, int64_t bt);
 bool mgp_dense1_eligible(const mgp_handle* h, int64_t n);
-bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n);
+bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n, int64_t bt);
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
                      int64_t max_it, int persist, int bt);

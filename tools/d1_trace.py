@@ -13,7 +13,7 @@ for n in (int(a) for a in sys.argv[2:]):
     g = torch.Generator(device="cpu").manual_seed(n)
     Z = torch.randn(n, 8, generator=g, dtype=torch.float64).to(dev)
     A = kernels.SquaredExponential(1.0, [1.0] * 8).K(Z) + 0.1 * torch.eye(n, dtype=torch.float64, device=dev)
-    B = torch.randn(1, n, generator=g, dtype=torch.float64).to(dev)
+    B = torch.randn(int(os.environ.get("D1_TRACE_BT", "1")), n, generator=g, dtype=torch.float64).to(dev)
     for rep in range(2):  # the second solve is the warm one
         conjugate_gradient(A, B, None, 0.0, max_iterations=40, max_steps_cycle=41, check_every=40)
     torch.cuda.synchronize()
