@@ -534,7 +534,9 @@ int pcg_solve_t(mgp_handle* h, const mgp_operator* op, const mgp_precond* pre, c
   // ... up to 8 where the full matrix fits the chip (n <= 2048: the register-resident form carries the columns for 16
   // fused multiply-adds each), else where the tile scheme was measured faster than the skinny product: 4, 6 above 4096
   const long d1_cols = h->cg_dense1_cols > 0 ? h->cg_dense1_cols
-                       : ((!h->d1_persist_off && mgp_dense1_persist_eligible(h, n, 8)) ? 8 : (n <= 4096 ? 4 : 6));
+                       : ((!h->d1_persist_off && mgp_dense1_persist_eligible(h, n, 8))   ? 8
+                          : (!h->d1_persist_off && mgp_dense1_persist_eligible(h, n, 6)) ? 6
+                                                                                         : (n <= 4096 ? 4 : 6));
   const bool dense1 = op->kind == MGP_OP_DENSE && Bt >= 1 && Bt <= d1_cols && !dense_pre &&
                       pc.kind != MGP_PRE_BLOCK && cycle > max_it && mgp_dense1_eligible(h, n);
   size_t bytes = (size_t)tot * sizeof(T) * (need_z ? 4 : 3) + (size_t)Bt * sizeof(T) + (size_t)Bt * sizeof(int) + 64 +

@@ -1007,6 +1007,354 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
   if (me == 0 && t == 0) ctrl->iters = k;
 }
 
+// ------------------------------------------------------------------ the triangle in 3 x 3 SUPER-BLOCKS of tiles
+// d1_persist_kernel deals the tiles of the triangle out round-robin: a workgroup's nine tiles touch eighteen chunks of
+// p, every tile publishes two 64-vectors (nt = 64 slots per chunk for the owner to read back), and each tile pays its
+// own cross-lane reduction.  Here workgroup (SI, SJ), SI <= SJ, holds the 3 x 3 tiles (3 SI + g, 3 SJ + ly): S =
+// ceil(nt / 3) <= 22 super-rows, S (S + 1) / 2 <= 253 workgroups -- the chip's 256 CUs, nine tiles each, as before.
+// Four-wave group g holds tile row I_g = 3 SI + g (wave wq its rows 16 wq .. 16 wq + 15), layer ly the tile column
+// J_ly = 3 SJ + ly (two layers in registers, the third in LDS).  Then
+//   * a workgroup needs SIX chunks of p (three when SI == SJ), not eighteen: a third of the z polls;
+//   * the row products of a wave's three tiles are added lane-locally BEFORE the cross-lane reduce-scatter -- one
+//     reduction per wave and column instead of three -- and the workgroup publishes ONE vector per tile row:
+//     sum_ly A_{I_g J_ly} p_{J_ly};
+//   * the column products (lane-local) of a tile column are summed over the workgroup's 12 waves in LDS and published
+//     as ONE vector per tile column: sum_g A_{I_g J_ly}^T p_{I_g} (diagonal tiles only in the row product);
+//   * chunk c of super-row s therefore collects S + 1 vectors (slot j < s: columns of block (j, s); j = s: rows of
+//     (s, s); s < j < S: rows of (s, j); j = S: columns of the diagonal block (s, s)) instead of nt = 64;
+//   * a further right-hand side costs 96 fused multiply-adds and one reduction per wave: BT <= 6 columns (the
+//     reference's 5 probes, models.py:286, at M = 4096), per column its own recurrence (:64-85) and guards (:68, :79),
+//     `any` over the columns as stopping rule (:59-62).
+// The owner of chunk c = 3 s + pos is a workgroup that holds p_c anyway: block (s, s + pos) (as a row chunk), or, where
+// s + pos >= S, block (s + pos - S, s) (as a column chunk) -- one chunk per workgroup for S >= 6.  Hand-offs, epochs,
+// bounds and fail-over as in d1_persist_kernel.  Granule arrays per column e: cg + e 128 W, zg + e n W, wpg + e 256 W,
+// Qg + e (nt (S + 1) 64) W with slot j of chunk c at ((c (S + 1) + j) 64) W.
+template <typename T, int BT>
+struct D1Blk {
+  static constexpr int kWpc = 12 / BT;                        // owner: polling waves per column
+  static constexpr int kUnits = 23 + 4;                       // <= S + 1 slot vectors + <= 4 x 64 workgroup shares
+  static constexpr int kUpw = (kUnits + kWpc - 1) / kWpc;     // 64-lane loads per polling wave
+  static constexpr size_t kTile = (size_t)3 * 64 * 64 * sizeof(T);
+  static constexpr size_t kColp = (size_t)3 * 12 * 64 * sizeof(T);  // one column's partial column products
+  static constexpr size_t kStatic = (size_t)(6 * BT + 2 * BT + 1 + 12) * 64 * sizeof(T) + 1024;
+  static constexpr int kColBuf = kTile + 2 * kColp + kStatic <= (size_t)160 * 1024 ? 2 : 1;
+  static constexpr size_t kDyn = kTile + kColBuf * kColp;
+};
+
+template <typename T, bool JAC, int BT>
+__global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
+                                                             const T* __restrict__ A, long n, int nt, int S,
+                                                             T* __restrict__ r, T* __restrict__ v,
+                                                             const T* __restrict__ dinv, T* __restrict__ cpart, T thr,
+                                                             T min_float, int max_it, int first_poll_sleep,
+                                                             unsigned long long* __restrict__ trace) {
+  constexpr int TS = 64;
+  constexpr int W = Gran<T>::W;
+  using Cfg = D1Blk<T, BT>;
+  constexpr int CB = Cfg::kColBuf, WPC = Cfg::kWpc, UPW = Cfg::kUpw;
+  const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..11
+  const int g = w >> 2, wq = w & 3;
+  const int me = (int)blockIdx.x;
+  auto stamp = [&](int it, int point) {
+    if (trace != nullptr && t == 0 && blockIdx.x < 2 && it < 64)
+      trace[((long)blockIdx.x * 64 + it) * 8 + point] = wall_clock64();
+  };
+  const int nblk = S * (S + 1) / 2;
+  if (me >= nblk) return;  // the rest of the grid leaves at once
+  int SI = 0, SJ = me;     // row-major over the upper triangle of super-blocks
+  while (SJ >= S - SI) {
+    SJ -= S - SI;
+    ++SI;
+  }
+  SJ += SI;
+  const bool diag = SI == SJ;
+  const int I = 3 * SI + g;                       // tile row of this four-wave group
+  const long qstride = (long)nt * (S + 1) * TS;   // elements of one column's slot vectors
+  __shared__ T pJ[3][BT][TS], pI[3][BT][TS];
+  __shared__ T rOwn[BT][TS], vOwn[BT][TS], dOwn[TS], shOwn[BT][2];
+  __shared__ T apP[12][TS], dP[12];     // owner: per polling wave its sum of slot vectors / of workgroup shares
+  __shared__ T gsum[BT][12], csum[BT][3];  // per column: the waves' shares of p.Ap from the row products, the layers' from the column products
+  __shared__ T sh_s[BT][3];             // per column: rz, ||r||^2 of the current residual, p.Ap
+  __shared__ T rzo_s[BT];               // per column: rz of the previous iteration
+  __shared__ int fail_s;
+  extern __shared__ __attribute__((aligned(16))) unsigned char d1b_dyn_lds[];
+  T(*a2s)[TS] = reinterpret_cast<T(*)[TS]>(d1b_dyn_lds) + (long)g * TS;  // rows of this group's third tile
+  T(*colp)[3][12][TS] = reinterpret_cast<T(*)[3][12][TS]>(d1b_dyn_lds + Cfg::kTile);  // [buffer][layer][wave][column]
+  if (t == 0) fail_s = 0;
+  for (int i = t; i < 3 * BT * TS; i += 768) {  // chunks beyond nt are never written again: 0 * p must be 0
+    (&pJ[0][0][0])[i] = 0;
+    (&pI[0][0][0])[i] = 0;
+  }
+  // ---- the tiles, ONCE: rows 16 wq .. 16 wq + 15 of tiles (I, 3 SJ + ly), lane = column; absent tiles and ragged edges
+  // are zeros (in a diagonal block the tiles below the diagonal, g > ly)
+  T a0[16], a1[16];
+#pragma unroll
+  for (int ly = 0; ly < 3; ++ly) {
+    const int J = 3 * SJ + ly;
+    const bool have = I < nt && J < nt && (!diag || g <= ly);
+    const long r0 = (long)(have ? I : 0) * TS + 16 * wq, c = (long)(have ? J : 0) * TS + l;
+    const long cj = c < n ? c : n - 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long row = r0 + q < n ? r0 + q : n - 1;
+      T x = A[row * n + cj];
+      x = (have && r0 + q < n && c < n) ? x : (T)0;
+      if (ly == 0) a0[q] = x;
+      else if (ly == 1) a1[q] = x;
+      else a2s[16 * wq + q][l] = x;
+    }
+  }
+  // ---- chunk ownership (see above)
+  int own = -1, opos = 0;
+  bool orole_j = false;
+  if (SJ - SI <= 2) {
+    own = 3 * SI + (SJ - SI);  // p_own = the row chunk g = SJ - SI (in a diagonal block that is column chunk 0 too)
+    opos = SJ - SI;
+  } else if (SI + S - SJ <= 2) {
+    opos = SI + S - SJ;        // wrapped: p_own = the column chunk ly = pos
+    own = 3 * SJ + opos;
+    orole_j = true;
+  }
+  if (own >= nt) own = -1;
+  const long oi = (long)(own >= 0 ? own : 0) * TS + l;
+  const bool ook = own >= 0 && oi < n;
+  if (own >= 0 && w < BT) {  // wave e: column e of the owner's chunk stays on the chip for the whole solve
+    rOwn[w][l] = ook ? r[(long)w * n + oi] : (T)0;
+    vOwn[w][l] = ook ? v[(long)w * n + oi] : (T)0;
+    if (w == 0) dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
+    if (l == 0) {
+      shOwn[w][0] = cpart[(long)w * 2 * CP + own];
+      shOwn[w][1] = cpart[(long)w * 2 * CP + CP + own];
+    }
+  }
+  const T(*pIr)[BT][TS] = diag ? pJ : pI;                                  // row chunks of a diagonal block ARE its column chunks
+  const T(*ownp)[TS] = orole_j ? pJ[opos] : pIr[opos];                     // [column][element] of p_own
+  // duties of the B phase, eight per column e (d = 8 e + j) over the twelve waves: j = 0, 1: the chunks' shares of rz /
+  // of ||r||^2; j = 2..4: z of column chunk j - 2 (-> p_J); j = 5..7: z of row chunk j - 5 (-> p_I; none in a diagonal block)
+  constexpr int ND = 8 * BT, DPW = (ND + 11) / 12;
+  if (t < BT) rzo_s[t] = 0;  // 0 makes p_1 = z_0 (the beta-term dropped, :79-84)
+  int k = 0;
+  __syncthreads();
+  while (true) {
+    long kz = 0;  // see d1_persist_kernel
+    asm volatile("" : "+s"(kz));
+    stamp(k, 0);
+    // ================================================================= B_k
+    const unsigned eb = (unsigned)k + 1u;
+    T dv[DPW];
+    {
+      bool ok = false;
+      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+        bool mine = true;
+#pragma unroll
+        for (int s = 0; s < DPW; ++s) {
+          const int d = w + 12 * s, e = d >> 3, j = d & 7;
+          dv[s] = 0;
+          if (d >= ND) continue;
+          if (j < 2) {
+            if (l < nt) mine = Gran<T>::load(grs, pb.cg + ((long)e * 128 + 64 * j + l + kz) * W, eb, dv[s]) && mine;
+          } else {
+            const int c = j < 5 ? 3 * SJ + j - 2 : 3 * SI + j - 5;
+            const long el = (long)c * TS + l + kz;
+            if (!(j >= 5 && diag) && c < nt && el < n)
+              mine = Gran<T>::load(grs, pb.zg + ((long)e * n + el) * W, eb, dv[s]) && mine;
+          }
+        }
+        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok && l == 0) fail_s = 1;
+#pragma unroll
+      for (int s = 0; s < DPW; ++s) {
+        const int d = w + 12 * s, e = d >> 3, j = d & 7;
+        if (d < ND && j < 2) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
+          const T sum = wave_allsum_valu(dv[s]);
+          if (l == 0) sh_s[e][j] = sum;
+        }
+      }
+    }
+    __syncthreads();
+    stamp(k, 1);
+    if (fail_s) break;
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < BT; ++e) any = any || (T)0.5 * sh_s[e][1] > thr;
+    if (!(any && k < max_it)) break;  // :59-62
+#pragma unroll
+    for (int s = 0; s < DPW; ++s) {
+      const int d = w + 12 * s, e = d >> 3, j = d & 7;
+      if (d < ND && j >= 2) {
+        const int c = j < 5 ? 3 * SJ + j - 2 : 3 * SI + j - 5;
+        if (!(j >= 5 && diag) && c < nt) {
+          T* dst = j < 5 ? pJ[j - 2][e] : pI[j - 5][e];
+          const T ro = rzo_s[e], rn = sh_s[e][0];
+          const bool drop = ro <= min_float;  // :79, per column
+          const T beta = drop ? (T)0 : rn / ro;
+          dst[l] = drop ? dv[s] : mgp_fma(beta, dst[l], dv[s]);  // a select, not 0 * p
+        }
+      }
+    }
+    lds_barrier();
+    if (t < BT) rzo_s[t] = sh_s[t][0];  // read again only after the next B phase's barrier
+    stamp(k, 2);
+    // ================================================================= tile products, epoch k + 1, column by column
+    const unsigned ea = (unsigned)k + 1u;
+#pragma nounroll
+    for (int e = 0; e < BT; ++e) {
+      const int cb = CB == 2 ? (e & 1) : 0;
+      const T pj0 = pJ[0][e][l], pj1 = pJ[1][e][l], pj2 = pJ[2][e][l];
+      T x[16];
+      T cs0 = 0, cs1 = 0, cs2 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const T a2lo = a2s[16 * wq + q][l], a2hi = a2s[16 * wq + q + 8][l];
+        const T pilo = pIr[g][e][16 * wq + q], pihi = pIr[g][e][16 * wq + q + 8];  // LDS broadcast reads
+        T lo = a0[q] * pj0, hi = a0[q + 8] * pj0;
+        lo = mgp_fma(a1[q], pj1, lo);
+        hi = mgp_fma(a1[q + 8], pj1, hi);
+        lo = mgp_fma(a2lo, pj2, lo);
+        hi = mgp_fma(a2hi, pj2, hi);
+        x[q] = rs_swap_add<true>(lo, hi);  // rows q and q + 8 meet across lane bit 32
+        cs0 = mgp_fma(a0[q], pilo, cs0);
+        cs1 = mgp_fma(a1[q], pilo, cs1);
+        cs2 = mgp_fma(a2lo, pilo, cs2);
+        cs0 = mgp_fma(a0[q + 8], pihi, cs0);
+        cs1 = mgp_fma(a1[q + 8], pihi, cs1);
+        cs2 = mgp_fma(a2hi, pihi, cs2);
+      }
+      if (CB == 1 && e > 0) lds_barrier();  // single buffer: the sums of column e - 1 have been read
+      // a diagonal tile enters through its row product only
+      colp[cb][0][w][l] = (diag && g == 0) ? (T)0 : cs0;
+      colp[cb][1][w][l] = (diag && g == 1) ? (T)0 : cs1;
+      colp[cb][2][w][l] = (diag && g == 2) ? (T)0 : cs2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = rs_swap_add<false>(x[q], x[q + 4]);  // lane bit 16
+      rs_step_row<T, 2, 8>(x, l);
+      rs_step_row<T, 1, 4>(x, l);
+      T sr = x[0];
+      sr += lane_xor_row<2>(sr);
+      sr += lane_xor_row<1>(sr);  // lane l: (sum_ly A_{I J_ly} p_{J_ly})[16 wq + (l >> 2)]
+      const int rr = 16 * wq + (l >> 2);
+      if ((l & 3) == 0 && I < nt && (long)I * TS + rr < n)
+        Gran<T>::store(grs, pb.Qg + ((long)e * qstride + ((long)I * (S + 1) + SJ) * TS + rr + kz) * W, ea, sr);
+      const T u = wave_allsum_valu((l & 3) == 0 ? sr * pIr[g][e][rr] : (T)0);
+      if (l == 0) gsum[e][w] = u;
+      lds_barrier();
+      // after the barrier of column e: three waves (rotating with e) sum a tile column's twelve partial products each and
+      // publish it; a fourth publishes the workgroup's share of p.Ap of column e - 1
+      const int w0 = (3 * e) % 12;
+      if (w >= w0 && w < w0 + 3) {
+        const int ly = w - w0, J = 3 * SJ + ly;
+        T sc = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < 3; ++g2)
+          sc += (colp[cb][ly][4 * g2][l] + colp[cb][ly][4 * g2 + 1][l]) + (colp[cb][ly][4 * g2 + 2][l] + colp[cb][ly][4 * g2 + 3][l]);
+        const long jc = (long)J * TS + l;
+        if (J < nt && jc < n)
+          Gran<T>::store(grs, pb.Qg + ((long)e * qstride + ((long)J * (S + 1) + (diag ? S : SI)) * TS + l + kz) * W, ea, sc);
+        const T cd = wave_allsum_valu(sc * pJ[ly][e][l]);  // p_J . (sum_g A_IJ^T p_I); p_J is 0 where there is no column
+        if (l == 0) csum[e][ly] = cd;
+      } else if (e > 0 && w == (w0 + 3) % 12 && l == 0) {
+        T sh = 0;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) sh += gsum[e - 1][q];
+        sh += (csum[e - 1][0] + csum[e - 1][1]) + csum[e - 1][2];
+        Gran<T>::store(grs, pb.wpg + ((long)(e - 1) * 256 + me + kz) * W, ea, sh);
+      }
+    }
+    lds_barrier();
+    if (t == 0) {
+      T sh = 0;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) sh += gsum[BT - 1][q];
+      sh += (csum[BT - 1][0] + csum[BT - 1][1]) + csum[BT - 1][2];
+      Gran<T>::store(grs, pb.wpg + ((long)(BT - 1) * 256 + me + kz) * W, ea, sh);
+    }
+    stamp(k, 3);
+    // ================================================================= the owner's update of iteration k + 1
+    if (own >= 0) {
+      // WPC waves per column read the chunk's S + 1 vectors and the workgroups' shares of p.Ap, all in one round trip.
+      // The first poll waits a little: one issued the moment this workgroup has published is served before the slowest
+      // producer's store has landed and costs a second round trip
+      {
+        const int e = w / WPC, sw = w - e * WPC;
+        if (e < BT) {
+          T val[UPW];
+          bool ok = false;
+          for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
+          for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+            bool mine = true;
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) {
+              const int u = sw * UPW + i;
+              val[i] = 0;
+              if (u <= S) {
+                if (ook)
+                  mine = Gran<T>::load(grs, pb.Qg + ((long)e * qstride + ((long)own * (S + 1) + u) * TS + l + kz) * W, ea, val[i]) && mine;
+              } else if (u <= S + 4) {
+                const int m = (u - S - 1) * 64 + l;
+                if (m < nblk) mine = Gran<T>::load(grs, pb.wpg + ((long)e * 256 + m + kz) * W, ea, val[i]) && mine;
+              }
+            }
+            ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok && l == 0) fail_s = 1;
+          T ap = 0, d = 0;  // in index order
+#pragma unroll
+          for (int i = 0; i < UPW; ++i) {
+            if (sw * UPW + i <= S) ap += val[i];
+            else d += val[i];
+          }
+          apP[w][l] = ap;
+          d = wave_allsum_valu(d);
+          if (l == 0) dP[w] = d;
+        }
+      }
+      __syncthreads();
+      if (fail_s) break;
+      stamp(k, 5);
+      if (w < BT) {  // wave e: column e
+        T ap = 0, d = 0;  // the polling waves in order
+#pragma unroll
+        for (int sw = 0; sw < WPC; ++sw) {
+          ap += apP[w * WPC + sw][l];
+          d += dP[w * WPC + sw];
+        }
+        const T gamma = (d <= min_float) ? (T)0 : sh_s[w][0] / d;  // :66-68 (rz of the residual the direction came from)
+        const T rc = mgp_fma(-gamma, ap, rOwn[w][l]);              // :76
+        const T zn = JAC ? rc * dOwn[l] : rc;                      // :77
+        if (ook) Gran<T>::store(grs, pb.zg + ((long)w * n + oi + kz) * W, ea + 1u, zn);
+        const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
+        if (l == 0) {
+          Gran<T>::store(grs, pb.cg + ((long)w * 128 + own + kz) * W, ea + 1u, prz);
+          Gran<T>::store(grs, pb.cg + ((long)w * 128 + 64 + own + kz) * W, ea + 1u, prr);
+          shOwn[w][0] = prz;
+          shOwn[w][1] = prr;
+        }
+        rOwn[w][l] = rc;
+        vOwn[w][l] = mgp_fma(gamma, ownp[w][l], vOwn[w][l]);  // :69
+      }
+      stamp(k, 7);
+    }
+    ++k;
+  }
+  if (own >= 0 && w < BT) {
+    if (ook) {
+      v[(long)w * n + oi] = vOwn[w][l];
+      r[(long)w * n + oi] = rOwn[w][l];
+    }
+    if (l == 0) {
+      cpart[(long)w * 2 * CP + own] = shOwn[w][0];
+      cpart[(long)w * 2 * CP + CP + own] = shOwn[w][1];
+    }
+  }
+  if (fail_s && t == 0) *pb.err = 1;
+  if (me == 0 && t == 0) ctrl->iters = k;
+}
+
 // ------------------------------------------------------------------ n <= 2048: the FULL matrix on the chip
 // At nt <= 32 tile rows all nt x nt tiles fit (1024 tiles, four per workgroup of 1024 threads), and a full tile row /
 // column set removes the expensive half of the triangle scheme: workgroup (J, rg) holds the tiles (I, J) of its row
@@ -1275,11 +1623,15 @@ int d1_layout(MgpDense1* st, void* arena, long n) {
   return MGP_OK;
 }
 
-// granule elements: Qg (triangle form: nt n; full form: bt nt 8 64 <= bt nt n / 8) | wpg bt 256 | cg bt 128 | zg bt n
-static size_t d1_gran_bytes(int dtype, long n, long bt) {
+// granule elements: Qg (round-robin triangle form: nt n; full form: bt nt 8 64; super-block form: bt nt (S + 1) 64 with
+// S + 1 <= 23) | wpg bt 256 | cg bt 128 | zg bt n
+static long d1_qg_elems(long n, long bt) {
   const long nt = (n + 63) / 64;
-  const long qg = nt * n > bt * nt * 8 * 64 ? nt * n : bt * nt * 8 * 64;
-  return (size_t)(qg + bt * (256 + 128 + n)) * (dtype == MGP_F64 ? 2 : 1) * sizeof(gu64);
+  const long blk = bt * nt * 23 * 64;
+  return nt * n > blk ? nt * n : blk;
+}
+static size_t d1_gran_bytes(int dtype, long n, long bt) {
+  return (size_t)(d1_qg_elems(n, bt) + bt * (256 + 128 + n)) * (dtype == MGP_F64 ? 2 : 1) * sizeof(gu64);
 }
 
 }  // namespace
@@ -1309,15 +1661,27 @@ static bool d1_full_geometry(const mgp_handle* h, long nt, int* R, int* rpg) {
   *rpg = g;
   return true;
 }
-bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n, int64_t bt) {
+// super-block form (d1_persist_blk_kernel): S = ceil(nt / 3) super-rows, one workgroup per block of the upper triangle;
+// S >= 6 so that every chunk finds an owner of its own among the blocks that hold it
+static bool d1_blk_geometry(const mgp_handle* h, long nt, int* S) {
+  const long s = (nt + 2) / 3;
+  if (nt > 64 || s < 6 || s * (s + 1) / 2 > d1_persist_grid(h)) return false;
+  *S = (int)s;
+  return true;
+}
+// which register-resident form a solve takes: 1 = full matrix, 2 = super-blocks, 3 = round-robin triangle, 0 = none
+// (MGP_CG_DENSE1: 3 = the best form, 4 = no full-matrix form, 5 = the round-robin triangle only)
+static int d1_persist_form(const mgp_handle* h, long n, long bt) {
   const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
   const int G = d1_persist_grid(h);
-  if (h->cg_dense1 < 3 || !mgp_dense1_eligible(h, n) || bt < 1 || bt > 8) return false;
-  int R = 0, rpg = 0;
-  const bool full = h->cg_dense1 != 4 && d1_full_geometry(h, nt, &R, &rpg);
-  if (bt > 1) return full;  // several columns: the full-matrix form only (no cross-lane work per column)
-  return full || (nt <= 64 && nt <= G && ntiles <= 9L * G);
+  if (h->cg_dense1 < 3 || !mgp_dense1_eligible(h, n) || bt < 1 || bt > 8) return 0;
+  int R = 0, rpg = 0, S = 0;
+  if (h->cg_dense1 == 3 && d1_full_geometry(h, nt, &R, &rpg)) return 1;
+  if (h->cg_dense1 <= 4 && bt <= 6 && d1_blk_geometry(h, nt, &S)) return 2;
+  if (bt == 1 && nt <= 64 && nt <= G && ntiles <= 9L * G) return 3;
+  return 0;
 }
+bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n, int64_t bt) { return d1_persist_form(h, n, bt) != 0; }
 
 int mgp_dense1_begin(mgp_handle* h, MgpDense1* st, int dtype, const void* A, int64_t n, const void* B, const void* av,
                      void* V, void* r, const void* dinv, MgpCgCtrl* ctrl, void* arena, double thr, double min_float,
@@ -1372,9 +1736,9 @@ template <typename T>
 static D1PBuf d1_pbuf(const MgpDense1* st) {
   constexpr long W = Gran<T>::W;
   D1PBuf pb;
-  const long bt = st->bt, qtri = (long)st->nt * st->n, qfull = bt * st->nt * 8 * 64;
+  const long bt = st->bt;
   pb.Qg = (gu64*)st->gran;
-  pb.wpg = pb.Qg + (qtri > qfull ? qtri : qfull) * W;
+  pb.wpg = pb.Qg + d1_qg_elems((long)st->n, bt) * W;
   pb.cg = pb.wpg + bt * 256 * W;
   pb.zg = pb.cg + bt * 128 * W;
   pb.err = (int*)st->sync;
@@ -1401,9 +1765,31 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     MGP_HIP(h, hipMemsetAsync(trace, 0, kTraceWords * sizeof(unsigned long long), h->stream));
   }
   // n <= 2048 (nt <= 32): the full matrix on the chip, four tiles per workgroup (d1_persist_full_kernel, 1..8 columns)
-  int Rg = 0, rpg = 0;
-  const bool full = h->cg_dense1 != 4 && d1_full_geometry(h, st->nt, &Rg, &rpg);
-  if (st->bt > 1 && !full) return mgp_fail(h, MGP_E_BADARG, "dense CG: several columns need the full-matrix form");
+  int Rg = 0, rpg = 0, Sb = 0;
+  const int form = d1_persist_form(h, (long)st->n, st->bt);
+  const bool full = form == 1 && d1_full_geometry(h, st->nt, &Rg, &rpg);
+  const bool blk = form == 2 && d1_blk_geometry(h, st->nt, &Sb);
+  if (form == 0 || (st->bt > 1 && !full && !blk))
+    return mgp_fail(h, MGP_E_BADARG, "dense CG: no register-resident form for n = %ld with %d columns", (long)st->n, st->bt);
+#define MGP_D1B(TT, JV, BTV)                                                                                         \
+  do {                                                                                                               \
+    const size_t dyn = D1Blk<TT, BTV>::kDyn;                                                                         \
+    MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_blk_kernel<TT, JV, BTV>,                                  \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                           \
+    hipLaunchKernelGGL((d1_persist_blk_kernel<TT, JV, BTV>), grid, dim3(768), dyn, h->stream, st->ctrl,                \
+                       d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Sb, (TT*)st->r, (TT*)st->V,            \
+                       (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
+                       h->d1_first_poll_sleep, trace);                                                               \
+  } while (0)
+#define MGP_D1BB(TT, JV)                     \
+  switch (st->bt) {                          \
+    case 1: MGP_D1B(TT, JV, 1); break;       \
+    case 2: MGP_D1B(TT, JV, 2); break;       \
+    case 3: MGP_D1B(TT, JV, 3); break;       \
+    case 4: MGP_D1B(TT, JV, 4); break;       \
+    case 5: MGP_D1B(TT, JV, 5); break;       \
+    default: MGP_D1B(TT, JV, 6); break;      \
+  }
 #define MGP_D1F(TT, JV, BTV)                                                                                         \
   do {                                                                                                               \
     const size_t dyn = (size_t)BTV * 16 * 64 * sizeof(TT);                                                           \
@@ -1431,6 +1817,10 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
       MGP_D1FB(TT, JV);                                                                                             \
       break;                                                                                                        \
     }                                                                                                               \
+    if (blk) {                                                                                                      \
+      MGP_D1BB(TT, JV);                                                                                             \
+      break;                                                                                                        \
+    }                                                                                                               \
   MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_kernel<TT, JV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)(3 * 64 * 64 * sizeof(TT))));                                                  \
   hipLaunchKernelGGL((d1_persist_kernel<TT, JV>), grid, dim3(768), 3 * 64 * 64 * sizeof(TT), h->stream, st->ctrl,     \
@@ -1448,6 +1838,8 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
   }
 #undef MGP_D1F
 #undef MGP_D1FB
+#undef MGP_D1B
+#undef MGP_D1BB
 #undef MGP_D1P
   MGP_LAUNCH_CHECK(h);
   if (trace) {  // diagnosis only: drains the stream
