@@ -417,6 +417,12 @@ def main():
             ((_, (psteps, _)), t_pcg) = timed(lambda: cgm.solve_with_stats(KL, probes))
             p_us = 1e3 * t_pcg / max(int(psteps), 1)
             p_flops, p_bytes = 2.0 * 64 * M * M, float(esize) * M * M
+            # ... and with the reference's DEFAULT probe count (CGGP(num_probes=5), models.py:286): what every prior_kl /
+            # eval_logdet of a training step runs
+            probes5 = probes[:, :5].contiguous()
+            cgm.solve_with_stats(KL, probes5)
+            ((_, (p5steps, _)), t_p5) = timed(lambda: cgm.solve_with_stats(KL, probes5))
+            p5_us = 1e3 * t_p5 / max(int(p5steps), 1)
             # the same one-RHS solve at C2's size (M = 2048)
             M2 = min(M, 2048)
             counts2 = counts[:M2].clone()
@@ -426,8 +432,10 @@ def main():
             ((_, (c2steps, _)), t_cg2) = timed(lambda: cgm.solve_with_stats(KL2, u2))
             it2_us = 1e3 * t_cg2 / max(int(c2steps), 1)
             tri2_bytes = esize * (M2 * (M2 + 64) / 2.0)
-            d1_form = {"3": "register-resident: the whole solve in one launch, the upper triangle of A held on the chip "
-                            "(csrc/cg_dense1.hip), n <= 4096", "1": "two launches per iteration"}.get(
+            d1_form = {"3": "register-resident: the whole solve in one launch, A held on the chip (csrc/cg_dense1.hip): the "
+                            "upper triangle in 3 x 3 super-blocks of tiles for 2048 < n <= 4096, the full matrix for "
+                            "n <= 2048", "4": "register-resident, super-blocks of the triangle at every n <= 4096",
+                       "1": "two launches per iteration"}.get(
                 os.environ.get("MGP_CG_DENSE1", "3"), "MGP_CG_DENSE1=" + os.environ.get("MGP_CG_DENSE1", ""))
             tri_bytes = esize * (M * (M + 64) / 2.0)  # the upper triangle's 64 x 64 tiles: what an iteration streams
             cdgp = {"assign_and_stats_ms": t_assign, "assign_and_stats_first_call_ms": t_assign_first,
@@ -445,6 +453,10 @@ def main():
                                        "Wall time of the whole solve / steps, start-up included"},
                     "cg_c2_size": {"M": M2, "cg_iterations": int(c2steps), "cg_ms": t_cg2, "cg_us_per_iteration": it2_us,
                                    "equivalent_GBps": tri2_bytes / (it2_us * 1e-6) / 1e9},
+                    "probe5_cg": {"columns": 5, "iterations": int(p5steps), "ms": t_p5, "us_per_iteration": p5_us,
+                                  "note": "the reference's default num_probes = 5 (models.py:286) on Kmm+Lambda: "
+                                          "register-resident form with 5 columns (round 3: skinny MFMA product + fused "
+                                          "update, 35 us per iteration)"},
                     "probe_cg": {"columns": 64, "iterations": int(psteps), "ms": t_pcg, "us_per_iteration": p_us,
                                  "tflops": p_flops / (p_us * 1e-6) / 1e12,
                                  "frac_of_fp64_mfma_peak": p_flops / (p_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,

@@ -625,25 +625,29 @@ using gu64 = unsigned long long;
 
 // ------------------------------------------------------------------ round 4: the matrix stays ON THE CHIP
 // For n <= 4096 the upper triangle of A (67 MB of 64 x 64 tiles at n = 4096) fits the register files of the chip
-// (256 CUs x 512 KB): one launch loads every tile ONCE -- a workgroup of 768 threads per CU (twelve waves, three per
-// SIMD) holds up to nine tiles, three per four-wave group: two in registers, 16 elements per lane and tile, one in
-// LDS -- and then runs
-// the WHOLE solve, conjugate_gradient.py:59-98, without touching A again.  What is left of an iteration is its two
-// global reductions, as hand-offs between resident workgroups in the form of cdna_hip_programming.md Guideline 16, R2 --
+// (256 CUs x 512 KB), for n <= 2048 the whole matrix: one launch loads every tile ONCE (d1_persist_blk_kernel: nine
+// tiles per workgroup of 768 threads, two per four-wave group in registers and one in LDS; d1_persist_full_kernel: four
+// per workgroup of 1024 threads) and then runs the WHOLE solve, conjugate_gradient.py:59-98, without touching A again.
+// What is left of an iteration is its two global reductions, as hand-offs between resident workgroups in the form of
+// cdna_hip_programming.md Guideline 16, R2 --
 // THE DATA IS THE FLAG: every published number travels as 8-byte granules {epoch, 32 bits of the value}, each written
-// by ONE write-through (sc1) 8-byte store and re-read with sc1 loads until its tag is the epoch the reader waits for.
+// by ONE write-through (sc1) store and re-read with sc1 loads until its tag is the epoch the reader waits for.
 // No flag word, no fence, no atomic, no drain-then-signal: a consumer's poll IS its data load, so a phase costs one
 // memory round trip after the last producer's store has landed (the flag form measured 13.3 us per iteration at
 // n = 4096: four dependent round trips of ~1.5 us each).
-//   A_k  every workgroup -> the chunk owners: the tiles' slots Q and one share of p.Ap per workgroup, epoch k + 1
+//   A_k  every workgroup -> the chunk owners: its partial vectors of A p and one share of p.Ap, epoch k + 1
 //   B_k  the chunk owners -> every workgroup: z = M^-1 r of the chunk and its shares of rz, ||r||^2, epoch k + 2
-//        (epoch 1 = the initial residual, written by d1_init_kernel)
-// Every wave forms the stopping rule (:59-62) and beta from the same 2 nt shares, so all workgroups leave the loop on
-// the same iteration with no further word exchanged.  A buffer is rewritten only after every reader has published
-// something that depends on having read it (slots and shares of p.Ap: read before an owner publishes B; z and the
-// chunk shares: read before a workgroup publishes A), so single buffers suffice and a reader never meets a later
+//        (epoch 1 = the initial residual, written by d1_persist_seed_kernel)
+// Every workgroup forms the stopping rule (:59-62) and beta from the same 2 nt shares, so all leave the loop on the
+// same iteration with no further word exchanged.  A buffer is rewritten only after every reader has published
+// something that depends on having read it (partial vectors and shares of p.Ap: read before an owner publishes B; z and
+// the chunk shares: read before a workgroup publishes A), so single buffers suffice and a reader never meets a later
 // epoch.  Every wait is bounded (a poll budget, then the error word and out): a workgroup that is not resident --
-// another stream holding CUs -- makes the solve fail over to the two-launch form, never hang.
+// another stream holding CUs -- makes the solve fail over to the two-launch form, never hang.  Who polls matters: a
+// wave polls only what it has a duty for, everybody else waits at the workgroup barrier (3072 waves re-reading all
+// shares every round trip were ~10 TB/s of write-through-line reads, 15.5 us per iteration).  Loop-carried per-wave
+// state lives in LDS, not registers: a spill reload forces `s_waitcnt vmcnt(0)`, i.e. a wait for the wave's own
+// write-through stores.
 constexpr int kPersistBudget = 1 << 16;  // polls of >= 1 us each
 
 // The granule region of a solve as ONE buffer resource: a 16-byte `buffer_load/store_dwordx4 ... sc1` moves both
@@ -676,6 +680,16 @@ struct Gran<double> {
     v = __hiloint2double((int)x.z, (int)x.x);
     return x.y == epoch && x.w == epoch;
   }
+  // the two halves of `load`, for polls that issue all their loads before looking at any tag (poll_units)
+  using Raw = d1_v4u;
+  static constexpr int kBytes = 16;
+  static __device__ __forceinline__ Raw raw(const GranRs& R, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(R.rs, voff, soff, 16);
+  }
+  static __device__ __forceinline__ bool unpack(const Raw& x, unsigned epoch, double& v) {
+    v = __hiloint2double((int)x.z, (int)x.x);
+    return (x.y == epoch) & (x.w == epoch);
+  }
 };
 template <>
 struct Gran<float> {
@@ -689,7 +703,79 @@ struct Gran<float> {
     v = __int_as_float((int)x.x);
     return x.y == epoch;
   }
+  using Raw = d1_v2u;
+  static constexpr int kBytes = 8;
+  static __device__ __forceinline__ Raw raw(const GranRs& R, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(R.rs, voff, soff, 16);
+  }
+  static __device__ __forceinline__ bool unpack(const Raw& x, unsigned epoch, float& v) {
+    v = __int_as_float((int)x.x);
+    return x.y == epoch;
+  }
 };
+
+// A poll of U elements per lane: every round issues its U loads BACK TO BACK and only then looks at the tags.  With a
+// branch between two loads (a guard per load) the compiler must end each basic block with `s_waitcnt vmcnt(0)`, and a
+// poll of U elements costs U dependent round trips instead of one -- measured: 2.5-3 us per right-hand side.  So a
+// load that is not needed (a lane beyond n, a unit beyond the count) is issued all the same, at an offset inside the
+// granule region, and only its tag is ignored.  Element i is at byte vo[i] (per lane) + so[i] (wave-uniform) of the
+// region.  Bounded; returns false when the budget ran out.  Elements not needed come back as 0.
+// ... with offsets and needs given as functions of (unit, an opaque zero renewed every round): nothing about the units
+// is loop-invariant to the compiler, so it keeps neither U offsets nor U lane masks in registers across the rounds
+// (fourteen units per wave at five and six columns: the difference between spilling and not)
+template <typename T, int U, typename VoFn, typename SoFn, typename NeedFn>
+__device__ __forceinline__ bool poll_units_fn(const GranRs& R, VoFn vo, SoFn so, NeedFn need, unsigned epoch, T (&val)[U]) {
+  bool ok = false;
+  unsigned long long needed = 0;  // per lane: bit i = unit i was needed (for the zeroing below)
+  for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    typename Gran<T>::Raw raw[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) raw[i] = Gran<T>::raw(R, vo(i, z), __builtin_amdgcn_readfirstlane(so(i, z)));
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < U; ++i) asm volatile("" : "+v"(raw[i]));
+    bool mine = true;
+    unsigned nd = 0;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const bool nd_i = need(i, z);
+      mine = mine & (Gran<T>::unpack(raw[i], epoch, val[i]) | !nd_i);
+      nd |= nd_i ? (1u << i) : 0u;
+    }
+    needed = nd;
+    ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+    if (!ok) __builtin_amdgcn_s_sleep(2);
+  }
+#pragma unroll
+  for (int i = 0; i < U; ++i) val[i] = ((needed >> i) & 1) ? val[i] : (T)0;
+  return ok;
+}
+
+template <typename T, int U>
+__device__ __forceinline__ bool poll_units(const GranRs& R, const int (&vo)[U], const int (&so)[U], const bool (&need)[U],
+                                           unsigned epoch, T (&val)[U]) {
+  bool ok = false;
+  for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
+    typename Gran<T>::Raw raw[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) raw[i] = Gran<T>::raw(R, vo[i], __builtin_amdgcn_readfirstlane(so[i]));
+    // ... and the scheduler must not interleave them with the tag tests either (it does, to save registers): no load
+    // moves below the first statement, no use of a loaded value above the ones after it
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < U; ++i) asm volatile("" : "+v"(raw[i]));
+    bool mine = true;
+#pragma unroll
+    for (int i = 0; i < U; ++i) mine = mine & (Gran<T>::unpack(raw[i], epoch, val[i]) | !need[i]);
+    ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+    if (!ok) __builtin_amdgcn_s_sleep(2);
+  }
+#pragma unroll
+  for (int i = 0; i < U; ++i) val[i] = need[i] ? val[i] : (T)0;
+  return ok;
+}
 
 // granule arrays of one solve (zeroed by mgp_dense1_begin: a tag left by an earlier solve must never match)
 struct D1PBuf {
@@ -717,300 +803,11 @@ __global__ __launch_bounds__(64) void d1_persist_seed_kernel(const T* __restrict
   }
 }
 
-template <typename T, bool JAC>
-__global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
-                                                         const T* __restrict__ A, long n, int nt, long ntiles,
-                                                         T* __restrict__ r, T* __restrict__ v,
-                                                         const T* __restrict__ dinv, T* __restrict__ cpart,
-                                                         const int2* __restrict__ tab, T thr, T min_float, int max_it,
-                                                         int first_poll_sleep, unsigned long long* __restrict__ trace) {
-  constexpr int TS = 64;
-  constexpr int W = Gran<T>::W;
-  const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..11: twelve waves, three per SIMD, up to 168 VGPRs each
-  // diagnosis (MGP_D1_TRACE=<file>): thread 0 of workgroups 0 (owner of chunk 0) and 1 (no chunk) stamps the 100 MHz
-  // constant counter at points of the first 64 iterations: trace[wg][iteration][point]
-  auto stamp = [&](int it, int point) {
-    if (trace != nullptr && t == 0 && blockIdx.x < 2 && it < 64)
-      trace[((long)blockIdx.x * 64 + it) * 8 + point] = wall_clock64();
-  };
-  const int g = w >> 2, wq = w & 3;                       // four-wave group (0..2), wave in the group
-  const int G = (int)gridDim.x, me = (int)blockIdx.x;
-  __shared__ T pJ[9][TS], pI[9][TS], pOwn[TS];
-  __shared__ T colp[3][3][4][TS];   // [layer][group][wave][column]
-  __shared__ T gsum[3][3][4];       // [layer][group][wave]: share of p.Ap
-  __shared__ T part[12][TS];        // owner: slot sums per wave
-  __shared__ T rOwn[TS], vOwn[TS], dOwn[TS], shOwn[2];  // owner: its chunk of r, v, 1/diag and its latest shares (LDS, not
-                                                       // registers: loop-carried values of one wave spill in all twelve)
-  __shared__ T sh_s[3];  // rz, ||r||^2 of the current residual (from wave 0), p.Ap (from the owner's polling wave)
-  __shared__ int fail_s;
-  // third tile of each four-wave group: 3 x 64 x 64 elements of dynamic LDS (96 KB in fp64) -- three REGISTER layers
-  // (96 VGPRs in fp64) left ~70 for everything else and the loop spilled; a reload in the owner's update forces
-  // `s_waitcnt vmcnt(0)`, i.e. a wait for this wave's write-through stores: 2.8 us per iteration in the timeline
-  extern __shared__ __attribute__((aligned(16))) unsigned char d1p_dyn_lds[];
-  T(*a2s)[TS] = reinterpret_cast<T(*)[TS]>(d1p_dyn_lds) + (long)g * TS;  // rows of this group's tile
-  if (t == 0) fail_s = 0;
-  // ---- tiles of this workgroup: slot s = b / G for b = me + s G; slot s belongs to group s % 3, layer s / 3
-  const long nmine = ntiles > me ? (ntiles - me + G - 1) / G : 0;  // <= 9
-  int tI[3], tJ[3];
-#pragma unroll
-  for (int ly = 0; ly < 3; ++ly) {
-    const long s = (long)ly * 3 + g;
-    const bool have = s < nmine;
-    const int2 ij = tab[have ? me + s * G : 0];
-    tI[ly] = have ? ij.x : -1;
-    tJ[ly] = have ? ij.y : -1;
-  }
-  // ---- load the tiles ONCE (rows 16 wq .. 16 wq + 15 of the tile, lane = column; ragged edges are zeros)
-  T a0[16], a1[16];
-#pragma unroll
-  for (int ly = 0; ly < 3; ++ly) {
-    const bool have = tI[ly] >= 0;
-    const long r0 = (long)(have ? tI[ly] : 0) * TS + 16 * wq, c = (long)(have ? tJ[ly] : 0) * TS + l;
-    const long cj = c < n ? c : n - 1;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const long row = r0 + q < n ? r0 + q : n - 1;
-      T x = A[row * n + cj];
-      x = (have && r0 + q < n && c < n) ? x : (T)0;
-      if (ly == 0) a0[q] = x;
-      else if (ly == 1) a1[q] = x;
-      else a2s[16 * wq + q][l] = x;
-    }
-  }
-  // ---- chunk ownership: chunk c belongs to workgroup (37 c) mod G -- spread over the XCDs; G >= nt
-  int own = -1;
-  for (int c = 0; c < nt; ++c)
-    if ((int)(((long)c * 37) % G) == me) own = c;
-  const long oi = (long)(own >= 0 ? own : 0) * TS + l;
-  const bool ook = own >= 0 && oi < n;
-  if (w == 0 && own >= 0) {  // the owner's chunk of r and v stays on the chip for the whole solve
-    rOwn[l] = ook ? r[oi] : (T)0;
-    vOwn[l] = ook ? v[oi] : (T)0;
-    dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
-    if (l == 0) {
-      shOwn[0] = cpart[own];
-      shOwn[1] = cpart[CP + own];
-    }
-  }
-  T rz_old = 0;  // rz of the previous iteration: 0 makes p_1 = z_0 (the beta-term dropped, :79-84)
-  int k = 0;     // completed iterations
-  __syncthreads();
-  while (true) {
-    // An opaque zero added to every index formed below: without it the compiler hoists some thirty loop-invariant
-    // 64-bit addresses out of the loop and spills them (the three register layers of the matrix leave ~70 VGPRs)
-    long kz = 0;
-    asm volatile("" : "+s"(kz));
-    stamp(k, 0);
-    // ================================================================= B_k: shares and z of the residual after k steps
-    // Who polls matters: 3072 waves re-reading all shares every round trip were ~10 TB/s of write-through-line reads
-    // and the owners' own loads and stores queued behind them (15.5 us per iteration).  ONE wave per workgroup polls the
-    // 2 nt shares; the waves with a duty poll only their own z chunk -- wave (g, wq) per layer: wq == 0 -> p_J of the
-    // group's tile, wq == 1 -> p_I; wave 11: the owner's chunk -- and everybody else waits at the workgroup barrier.
-    const unsigned eb = (unsigned)k + 1u;
-    T zj[3] = {0, 0, 0}, zo = 0;
-    {
-      const bool duty = (wq < 2 && tI[0] >= 0) || (w == 11 && own >= 0) || w == 0;
-      T z0 = 0, q0 = 0;
-      bool ok = !duty;
-      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-        bool mine = true;
-        if (w == 0 && l < nt) {
-          mine = Gran<T>::load(grs, pb.cg + (long)(l + kz) * W, eb, z0) && mine;
-          mine = Gran<T>::load(grs, pb.cg + (long)(64 + l + kz) * W, eb, q0) && mine;
-        }
-#pragma unroll
-        for (int ly = 0; ly < 3; ++ly) {
-          if (tI[ly] >= 0 && wq < 2) {
-            const long e = (long)(wq == 0 ? tJ[ly] : tI[ly]) * TS + l + kz;
-            if (e < n) mine = Gran<T>::load(grs, pb.zg + e * W, eb, zj[ly]) && mine;
-          }
-        }
-        if (w == 11 && ook) mine = Gran<T>::load(grs, pb.zg + (oi + kz) * W, eb, zo) && mine;
-        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-        if (!ok) __builtin_amdgcn_s_sleep(2);
-      }
-      if (!ok && l == 0) fail_s = 1;
-      if (w == 0) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
-        const T a_rz = wave_allsum_valu(z0), a_rr = wave_allsum_valu(q0);
-        if (l == 0) {
-          sh_s[0] = a_rz;
-          sh_s[1] = a_rr;
-        }
-      }
-    }
-    __syncthreads();
-    stamp(k, 1);
-    if (fail_s) break;
-    const T rz_new = sh_s[0], rr_new = sh_s[1];
-    const bool live = (T)0.5 * rr_new > thr && k < max_it;  // :59-62
-    if (!live) break;
-    const bool drop = rz_old <= min_float;  // :79
-    const T beta = drop ? (T)0 : rz_new / rz_old;
-#pragma unroll
-    for (int ly = 0; ly < 3; ++ly) {
-      if (tI[ly] >= 0 && wq < 2) {
-        const int s = ly * 3 + g;
-        T* dst = wq == 0 ? pJ[s] : pI[s];
-        dst[l] = drop ? zj[ly] : mgp_fma(beta, dst[l], zj[ly]);  // a select, not 0 * p: LDS holds anything at start-up
-      }
-    }
-    if (w == 11 && own >= 0) pOwn[l] = drop ? zo : mgp_fma(beta, pOwn[l], zo);
-    rz_old = rz_new;
-    lds_barrier();
-    stamp(k, 2);
-    // ================================================================= tile products of iteration k + 1, epoch k + 1
-    const unsigned ea = (unsigned)k + 1u;
-#pragma unroll
-    for (int ly = 0; ly < 3; ++ly) {
-      if (tI[ly] >= 0) {  // uniform per group
-        const int s = ly * 3 + g;
-        const int I = tI[ly], J = tJ[ly];
-        const T pj = pJ[s][l];
-        // the first reduce-scatter step (rows q and q + 8 meet across lane bit 32) is taken as the products are formed:
-        // eight sums live instead of sixteen next to the three register layers of the matrix
-        T x[16];
-        T cs = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const T alo = ly == 0 ? a0[q] : (ly == 1 ? a1[q] : a2s[16 * wq + q][l]);
-          const T ahi = ly == 0 ? a0[q + 8] : (ly == 1 ? a1[q + 8] : a2s[16 * wq + q + 8][l]);
-          cs = mgp_fma(alo, pI[s][16 * wq + q], cs);  // the same address in every lane: an LDS broadcast read
-          x[q] = rs_swap_add<true>(alo * pj, ahi * pj);  // rows q and q + 8 meet across lane bit 32
-        }
-#pragma unroll
-        for (int q = 8; q < 16; ++q) {
-          const T aq = ly == 0 ? a0[q] : (ly == 1 ? a1[q] : a2s[16 * wq + q][l]);
-          cs = mgp_fma(aq, pI[s][16 * wq + q], cs);
-        }
-        colp[ly][g][wq][l] = cs;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = rs_swap_add<false>(x[q], x[q + 4]);  // lane bit 16
-        rs_step_row<T, 2, 8>(x, l);
-        rs_step_row<T, 1, 4>(x, l);
-        T sr = x[0];
-        sr += lane_xor_row<2>(sr);
-        sr += lane_xor_row<1>(sr);  // lane l: (A_IJ p_J)[16 wq + (l >> 2)]
-        const long i = (long)I * TS + 16 * wq + (l >> 2) + kz;
-        if ((l & 3) == 0 && i < n) Gran<T>::store(grs, pb.Qg + ((long)J * n + i) * W, ea, sr);
-        const T prow = pI[s][16 * wq + (l >> 2)];
-        const T u = wave_allsum_valu((l & 3) == 0 ? sr * prow : (T)0);
-        if (l == 0) gsum[ly][g][wq] = u;
-      }
-    }
-    lds_barrier();
-    T share = 0;
-#pragma unroll
-    for (int ly = 0; ly < 3; ++ly) {
-      if (tI[ly] >= 0) {
-        const int I = tI[ly], J = tJ[ly];
-        if (wq == ly && I != J) {  // the column sums of layer ly by wave ly of the group: three waves share the three layers
-          const T sc = (colp[ly][g][0][l] + colp[ly][g][1][l]) + (colp[ly][g][2][l] + colp[ly][g][3][l]);
-          const long ic2 = (long)J * TS + l + kz;
-          if (ic2 < n) Gran<T>::store(grs, pb.Qg + ((long)I * n + ic2) * W, ea, sc);
-        }
-        const T tot = (gsum[ly][g][0] + gsum[ly][g][1]) + (gsum[ly][g][2] + gsum[ly][g][3]);
-        share += I == J ? tot : tot + tot;  // the same in the four waves of the group
-      }
-    }
-    lds_barrier();
-    // the workgroup's share of p.Ap: per group its layers in order, then the groups in order
-    if (wq == 0 && l == 0) gsum[0][g][0] = share;
-    lds_barrier();
-    if (t == 0) Gran<T>::store(grs, pb.wpg + (long)(me + kz) * W, ea, (gsum[0][0][0] + gsum[0][1][0]) + gsum[0][2][0]);
-    stamp(k, 3);
-    // ================================================================= the owner's update of iteration k + 1
-    if (own >= 0) {
-      // ONE wave polls the workgroups' shares of p.Ap (4 KB a round); a workgroup stores its share after its slots, so
-      // when all 256 carry the epoch the slots are (all but surely) there: the other waves wait at the barrier and
-      // then read the chunk's slots once -- every granule still checked, a stale one re-read
-      if (w == 11) {
-        T tp[4] = {0, 0, 0, 0};
-        bool ok = false;
-        // not at once: a poll issued the moment this workgroup has published is served before the slowest producer's
-        // store has landed, and the next one costs a whole round trip more
-        for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
-        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-          bool mine = true;
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            if (m * 64 + l < G) mine = Gran<T>::load(grs, pb.wpg + (long)(m * 64 + l + kz) * W, ea, tp[m]) && mine;
-          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-          if (!ok) __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok && l == 0) fail_s = 1;
-        T d = 0;  // lane-sequential, then the butterfly
-#pragma unroll
-        for (int m = 0; m < 4; ++m) d += tp[m];
-        d = wave_allsum_valu(d);
-        if (l == 0) sh_s[2] = d;
-      }
-      __syncthreads();
-      stamp(k, 4);
-      // slots of the chunk: wave w adds slots 6 w .. 6 w + 5 (index order), then the waves in order
-      T sl[6] = {0, 0, 0, 0, 0, 0};
-      if (6 * w < nt) {
-        bool ok = false;
-        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-          bool mine = true;
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            if (6 * w + q < nt && oi < n)
-              mine = Gran<T>::load(grs, pb.Qg + ((long)(6 * w + q) * n + oi + kz) * W, ea, sl[q]) && mine;
-          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-          if (!ok) __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok && l == 0) fail_s = 1;
-      }
-      stamp(k, 5);
-      T sacc = 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) sacc += sl[q];
-      part[w][l] = sacc;
-      __syncthreads();
-      if (fail_s) break;
-      stamp(k, 6);
-      if (w == 0) {
-        const T d = sh_s[2];
-        const T gamma = (d <= min_float) ? (T)0 : rz_new / d;  // :66-68 (rz of the residual the direction was built from)
-        T ap = part[0][l];
-#pragma unroll
-        for (int q = 1; q < 12; ++q) ap += part[q][l];
-        const T rc = mgp_fma(-gamma, ap, rOwn[l]);  // :76
-        const T zn = JAC ? rc * dOwn[l] : rc;       // :77
-        if (ook) Gran<T>::store(grs, pb.zg + (oi + kz) * W, ea + 1u, zn);  // first: the critical path of everybody else
-        const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
-        if (l == 0) {
-          Gran<T>::store(grs, pb.cg + (long)(own + kz) * W, ea + 1u, prz);
-          Gran<T>::store(grs, pb.cg + (long)(64 + own + kz) * W, ea + 1u, prr);
-          shOwn[0] = prz;
-          shOwn[1] = prr;
-        }
-        rOwn[l] = rc;
-        vOwn[l] = mgp_fma(gamma, pOwn[l], vOwn[l]);  // :69
-      }
-      stamp(k, 7);
-    }
-    ++k;
-  }
-  // ---- out: the owners write their chunk of the solution and the residual and their shares; workgroup 0 the counters
-  if (w == 0 && ook) {
-    v[oi] = vOwn[l];
-    r[oi] = rOwn[l];
-  }
-  if (w == 0 && own >= 0 && l == 0) {
-    cpart[own] = shOwn[0];
-    cpart[CP + own] = shOwn[1];
-  }
-  if (fail_s && t == 0) *pb.err = 1;
-  if (me == 0 && t == 0) ctrl->iters = k;
-}
-
 // ------------------------------------------------------------------ the triangle in 3 x 3 SUPER-BLOCKS of tiles
-// d1_persist_kernel deals the tiles of the triangle out round-robin: a workgroup's nine tiles touch eighteen chunks of
-// p, every tile publishes two 64-vectors (nt = 64 slots per chunk for the owner to read back), and each tile pays its
-// own cross-lane reduction.  Here workgroup (SI, SJ), SI <= SJ, holds the 3 x 3 tiles (3 SI + g, 3 SJ + ly): S =
+// Dealt out round-robin (the first form of this kernel, 12.3 us per iteration at n = 4096 against 7.4 for this one in
+// the same run, profiles/r04_ab_dense1_super_blocks_first.txt), a workgroup's nine tiles touch eighteen chunks of p,
+// every tile publishes two 64-vectors (nt = 64 per chunk for the owner to read back), and each tile pays its own
+// cross-lane reduction.  Here workgroup (SI, SJ), SI <= SJ, holds the 3 x 3 tiles (3 SI + g, 3 SJ + ly): S =
 // ceil(nt / 3) <= 22 super-rows, S (S + 1) / 2 <= 253 workgroups -- the chip's 256 CUs, nine tiles each, as before.
 // Four-wave group g holds tile row I_g = 3 SI + g (wave wq its rows 16 wq .. 16 wq + 15), layer ly the tile column
 // J_ly = 3 SJ + ly (two layers in registers, the third in LDS).  Then
@@ -1027,7 +824,7 @@ __global__ __launch_bounds__(768) void d1_persist_kernel(MgpCgCtrl* __restrict__
 //     `any` over the columns as stopping rule (:59-62).
 // The owner of chunk c = 3 s + pos is a workgroup that holds p_c anyway: block (s, s + pos) (as a row chunk), or, where
 // s + pos >= S, block (s + pos - S, s) (as a column chunk) -- one chunk per workgroup for S >= 6.  Hand-offs, epochs,
-// bounds and fail-over as in d1_persist_kernel.  Granule arrays per column e: cg + e 128 W, zg + e n W, wpg + e 256 W,
+// bounds and fail-over as described above.  Granule arrays per column e: cg + e 128 W, zg + e n W, wpg + e 256 W,
 // Qg + e (nt (S + 1) 64) W with slot j of chunk c at ((c (S + 1) + j) 64) W.
 template <typename T, int BT>
 struct D1Blk {
@@ -1036,7 +833,7 @@ struct D1Blk {
   static constexpr int kUpw = (kUnits + kWpc - 1) / kWpc;     // 64-lane loads per polling wave
   static constexpr size_t kTile = (size_t)3 * 64 * 64 * sizeof(T);
   static constexpr size_t kColp = (size_t)3 * 12 * 64 * sizeof(T);  // one column's partial column products
-  static constexpr size_t kStatic = (size_t)(6 * BT + 2 * BT + 1 + 12) * 64 * sizeof(T) + 1024;
+  static constexpr size_t kStatic = (size_t)(6 * BT + 2 * BT + 1) * 64 * sizeof(T) + 1024;
   static constexpr int kColBuf = kTile + 2 * kColp + kStatic <= (size_t)160 * 1024 ? 2 : 1;
   static constexpr size_t kDyn = kTile + kColBuf * kColp;
 };
@@ -1052,14 +849,19 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   constexpr int W = Gran<T>::W;
   using Cfg = D1Blk<T, BT>;
   constexpr int CB = Cfg::kColBuf, WPC = Cfg::kWpc, UPW = Cfg::kUpw;
+  constexpr int GB = Gran<T>::kBytes;  // bytes of an element's granules
   const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
+  const int wpg_off = (int)((const char*)pb.wpg - (const char*)pb.Qg), cg_off = (int)((const char*)pb.cg - (const char*)pb.Qg),
+            zg_off = (int)((const char*)pb.zg - (const char*)pb.Qg);
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // 0..11
   const int g = w >> 2, wq = w & 3;
   const int me = (int)blockIdx.x;
+  // diagnosis (MGP_D1_TRACE=<file>): thread 0 of workgroups 0 (block (0, 0), owner of chunk 0) and 3 (block (0, 3), no
+  // chunk) stamps the 100 MHz constant counter at points of the first 64 iterations: trace[row][iteration][point]
+  const int trow = me == 0 ? 0 : (me == 3 ? 1 : -1);
   auto stamp = [&](int it, int point) {
-    if (trace != nullptr && t == 0 && blockIdx.x < 2 && it < 64)
-      trace[((long)blockIdx.x * 64 + it) * 8 + point] = wall_clock64();
+    if (trace != nullptr && t == 0 && trow >= 0 && it < 64) trace[((long)trow * 64 + it) * 8 + point] = wall_clock64();
   };
   const int nblk = S * (S + 1) / 2;
   if (me >= nblk) return;  // the rest of the grid leaves at once
@@ -1074,7 +876,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   const long qstride = (long)nt * (S + 1) * TS;   // elements of one column's slot vectors
   __shared__ T pJ[3][BT][TS], pI[3][BT][TS];
   __shared__ T rOwn[BT][TS], vOwn[BT][TS], dOwn[TS], shOwn[BT][2];
-  __shared__ T apP[12][TS], dP[12];     // owner: per polling wave its sum of slot vectors / of workgroup shares
+  __shared__ T dP[12];                  // owner: per polling wave its sum of workgroup shares
   __shared__ T gsum[BT][12], csum[BT][3];  // per column: the waves' shares of p.Ap from the row products, the layers' from the column products
   __shared__ T sh_s[BT][3];             // per column: rz, ||r||^2 of the current residual, p.Ap
   __shared__ T rzo_s[BT];               // per column: rz of the previous iteration
@@ -1082,6 +884,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char d1b_dyn_lds[];
   T(*a2s)[TS] = reinterpret_cast<T(*)[TS]>(d1b_dyn_lds) + (long)g * TS;  // rows of this group's third tile
   T(*colp)[3][12][TS] = reinterpret_cast<T(*)[3][12][TS]>(d1b_dyn_lds + Cfg::kTile);  // [buffer][layer][wave][column]
+  T(*apP)[TS] = reinterpret_cast<T(*)[TS]>(d1b_dyn_lds + Cfg::kTile);  // owner, [polling wave][element]: its sum of slot vectors -- in colp, which rests between the tile phases
   if (t == 0) fail_s = 0;
   for (int i = t; i < 3 * BT * TS; i += 768) {  // chunks beyond nt are never written again: 0 * p must be 0
     (&pJ[0][0][0])[i] = 0;
@@ -1138,33 +941,28 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   int k = 0;
   __syncthreads();
   while (true) {
-    long kz = 0;  // see d1_persist_kernel
+    long kz = 0;  // an opaque zero in every offset: loop-invariant addresses are not hoisted out of the solve and spilled
     asm volatile("" : "+s"(kz));
+    const int kzi = (int)kz;
     stamp(k, 0);
     // ================================================================= B_k
     const unsigned eb = (unsigned)k + 1u;
     T dv[DPW];
     {
-      bool ok = false;
-      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-        bool mine = true;
+      int vo[DPW], so[DPW];
+      bool need[DPW];
 #pragma unroll
-        for (int s = 0; s < DPW; ++s) {
-          const int d = w + 12 * s, e = d >> 3, j = d & 7;
-          dv[s] = 0;
-          if (d >= ND) continue;
-          if (j < 2) {
-            if (l < nt) mine = Gran<T>::load(grs, pb.cg + ((long)e * 128 + 64 * j + l + kz) * W, eb, dv[s]) && mine;
-          } else {
-            const int c = j < 5 ? 3 * SJ + j - 2 : 3 * SI + j - 5;
-            const long el = (long)c * TS + l + kz;
-            if (!(j >= 5 && diag) && c < nt && el < n)
-              mine = Gran<T>::load(grs, pb.zg + ((long)e * n + el) * W, eb, dv[s]) && mine;
-          }
-        }
-        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-        if (!ok) __builtin_amdgcn_s_sleep(2);
+      for (int s = 0; s < DPW; ++s) {
+        const int d = w + 12 * s, e = d >> 3, j = d & 7;
+        const bool sduty = d < ND && j < 2;
+        const int c = j < 5 ? 3 * SJ + (j >= 2 ? j - 2 : 0) : 3 * SI + j - 5;
+        const bool zduty = d < ND && j >= 2 && !(j >= 5 && diag) && c < nt;
+        const long el = (long)c * TS + l;
+        need[s] = sduty ? l < nt : (zduty && el < n);
+        so[s] = sduty ? cg_off + (e * 128 + 64 * j) * GB : (zduty ? zg_off + e * (int)n * GB : 0);
+        vo[s] = (sduty ? l : (zduty ? (int)(el < n ? el : n - 1) : 0)) * GB + kzi;
       }
+      const bool ok = poll_units<T, DPW>(grs, vo, so, need, eb, dv);
       if (!ok && l == 0) fail_s = 1;
 #pragma unroll
       for (int s = 0; s < DPW; ++s) {
@@ -1242,6 +1040,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
       const T u = wave_allsum_valu((l & 3) == 0 ? sr * pIr[g][e][rr] : (T)0);
       if (l == 0) gsum[e][w] = u;
       lds_barrier();
+      if (e == 0) stamp(k, 6);
       // after the barrier of column e: three waves (rotating with e) sum a tile column's twelve partial products each and
       // publish it; a fourth publishes the workgroup's share of p.Ap of column e - 1
       const int w0 = (3 * e) % 12;
@@ -1282,26 +1081,20 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
         const int e = w / WPC, sw = w - e * WPC;
         if (e < BT) {
           T val[UPW];
-          bool ok = false;
+          // unit u = sw UPW + i: u <= S: slot vector u of the chunk; S < u <= S + 4: 64 of the workgroups' shares
+          auto so_fn = [&](int i, int z) {
+            const int u = sw * UPW + i + z, m = (u - S - 1) * 64;
+            return u <= S ? (e * (int)qstride + (own * (S + 1) + u) * TS) * GB : (u <= S + 4 ? wpg_off + (e * 256 + m) * GB : 0);
+          };
+          auto vo_fn = [&](int, int z) { return (l + z) * GB; };
+          auto need_fn = [&](int i, int z) {
+            const int u = sw * UPW + i + z, m = (u - S - 1) * 64;
+            return u <= S ? ook : (u <= S + 4 && m + l < nblk);
+          };
           for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
-          for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-            bool mine = true;
-#pragma unroll
-            for (int i = 0; i < UPW; ++i) {
-              const int u = sw * UPW + i;
-              val[i] = 0;
-              if (u <= S) {
-                if (ook)
-                  mine = Gran<T>::load(grs, pb.Qg + ((long)e * qstride + ((long)own * (S + 1) + u) * TS + l + kz) * W, ea, val[i]) && mine;
-              } else if (u <= S + 4) {
-                const int m = (u - S - 1) * 64 + l;
-                if (m < nblk) mine = Gran<T>::load(grs, pb.wpg + ((long)e * 256 + m + kz) * W, ea, val[i]) && mine;
-              }
-            }
-            ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-            if (!ok) __builtin_amdgcn_s_sleep(2);
-          }
+          const bool ok = poll_units_fn<T, UPW>(grs, vo_fn, so_fn, need_fn, ea, val);
           if (!ok && l == 0) fail_s = 1;
+          stamp(k, 4);
           T ap = 0, d = 0;  // in index order
 #pragma unroll
           for (int i = 0; i < UPW; ++i) {
@@ -1365,7 +1158,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
 // and the workgroups' shares of p.Ap in the SAME round trip.  With no cross-lane work a further right-hand side costs
 // 16 fused multiply-adds per tile and wave, so the form carries BT <= 8 columns (the reference's default of 5 probes,
 // models.py:286, at C2's M = 2048): per column its own recurrence (:64-85) and guards (:68, :79), `any` over the
-// columns as stopping rule (:59-62).  Hand-offs, epochs, bounds and fail-over as in d1_persist_kernel.  Granule arrays
+// columns as stopping rule (:59-62).  Hand-offs, epochs, bounds and fail-over as described above.  Granule arrays
 // per column e: cg + e 128 W, zg + e n W, wpg + e 256 W, Qg + e (nt R 64) W.
 template <typename T, bool JAC, int BT>
 __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __restrict__ ctrl, D1PBuf pb,
@@ -1423,54 +1216,46 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
       shOwn[w][1] = cpart[(long)w * 2 * CP + CP + J];
     }
   }
-  // duties of the B phase, spread over the sixteen waves: duty d < BT: the shares of column d; BT <= d < 2 BT: z of
-  // chunk J, column d - BT (-> p_J); 2 BT <= d < 6 BT: z of tile row I_g, column e (-> p_I[g]), d = 2 BT + 4 e + g
-  constexpr int ND = 6 * BT, DPW = (ND + 15) / 16;  // duties per wave
+  // duties of the B phase, spread over the sixteen waves: duty d < BT: the chunks' shares of rz, column d; < 2 BT: of
+  // ||r||^2; < 3 BT: z of chunk J (-> p_J); then z of tile row I_g, column e (-> p_I[g]), d = 3 BT + 4 e + g
+  constexpr int ND = 7 * BT, DPW = (ND + 15) / 16;  // duties per wave
+  constexpr int GB = Gran<T>::kBytes;
+  const int wpg_off = (int)((const char*)pb.wpg - (const char*)pb.Qg), cg_off = (int)((const char*)pb.cg - (const char*)pb.Qg),
+            zg_off = (int)((const char*)pb.zg - (const char*)pb.Qg);
   if (t < BT) rzo_s[t] = 0;  // 0 makes p_1 = z_0 (the beta-term dropped, :79-84)
   int k = 0;
   __syncthreads();
   while (true) {
-    long kz = 0;  // see d1_persist_kernel
+    long kz = 0;  // an opaque zero in every offset: loop-invariant addresses are not hoisted out of the solve and spilled
     asm volatile("" : "+s"(kz));
+    const int kzi = (int)kz;
     stamp(k, 0);
     // ================================================================= B_k
     const unsigned eb = (unsigned)k + 1u;
-    T dv[DPW][2];  // a duty's values: shares -> (rz share, rr share); z -> (z, -)
+    T dv[DPW];
     {
-      bool ok = false;
-      for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-        bool mine = true;
+      int vo[DPW], so[DPW];
+      bool need[DPW];
 #pragma unroll
-        for (int s = 0; s < DPW; ++s) {
-          const int d = w + 16 * s;
-          dv[s][0] = dv[s][1] = 0;
-          if (d < BT) {
-            if (l < nt) {
-              mine = Gran<T>::load(grs, pb.cg + ((long)d * 128 + l + kz) * W, eb, dv[s][0]) && mine;
-              mine = Gran<T>::load(grs, pb.cg + ((long)d * 128 + 64 + l + kz) * W, eb, dv[s][1]) && mine;
-            }
-          } else if (d < 2 * BT) {
-            if (ook) mine = Gran<T>::load(grs, pb.zg + ((long)(d - BT) * n + oi + kz) * W, eb, dv[s][0]) && mine;
-          } else if (d < ND) {
-            const int e = (d - 2 * BT) >> 2, g2 = (d - 2 * BT) & 3;
-            const int I2 = rg * rpg + g2;
-            const long el = (long)I2 * TS + l + kz;
-            if (g2 < rpg && I2 < nt && el < n) mine = Gran<T>::load(grs, pb.zg + ((long)e * n + el) * W, eb, dv[s][0]) && mine;
-          }
-        }
-        ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-        if (!ok) __builtin_amdgcn_s_sleep(2);
+      for (int s = 0; s < DPW; ++s) {
+        const int d = w + 16 * s;
+        const bool sduty = d < 2 * BT, jduty = !sduty && d < 3 * BT, iduty = d >= 3 * BT && d < ND;
+        const int e = sduty ? (d < BT ? d : d - BT) : (jduty ? d - 2 * BT : (d - 3 * BT) >> 2);
+        const int g2 = (d - 3 * BT) & 3, I2 = rg * rpg + g2;
+        const bool irow = iduty && g2 < rpg && I2 < nt;
+        const long el = jduty ? oi : (long)(irow ? I2 : 0) * TS + l;
+        need[s] = sduty ? l < nt : ((jduty || irow) && el < n);
+        so[s] = sduty ? cg_off + (e * 128 + (d < BT ? 0 : 64)) * GB : ((jduty || irow) ? zg_off + e * (int)n * GB : 0);
+        vo[s] = (sduty ? l : ((jduty || irow) ? (int)(el < n ? el : n - 1) : 0)) * GB + kzi;
       }
+      const bool ok = poll_units<T, DPW>(grs, vo, so, need, eb, dv);
       if (!ok && l == 0) fail_s = 1;
 #pragma unroll
       for (int s = 0; s < DPW; ++s) {
         const int d = w + 16 * s;
-        if (d < BT) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
-          const T a_rz = wave_allsum_valu(dv[s][0]), a_rr = wave_allsum_valu(dv[s][1]);
-          if (l == 0) {
-            sh_s[d][0] = a_rz;
-            sh_s[d][1] = a_rr;
-          }
+        if (d < 2 * BT) {  // the same sums, in the same order, as the statistics kernel forms from the plain shares
+          const T sum = wave_allsum_valu(dv[s]);
+          if (l == 0) sh_s[d < BT ? d : d - BT][d < BT ? 0 : 1] = sum;
         }
       }
     }
@@ -1484,13 +1269,13 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
 #pragma unroll
     for (int s = 0; s < DPW; ++s) {
       const int d = w + 16 * s;
-      if (d >= BT && d < ND) {
-        const int e = d < 2 * BT ? d - BT : (d - 2 * BT) >> 2;
-        T* dst = d < 2 * BT ? pJ[e] : pI[(d - 2 * BT) & 3][e];
+      if (d >= 2 * BT && d < ND) {
+        const int e = d < 3 * BT ? d - 2 * BT : (d - 3 * BT) >> 2;
+        T* dst = d < 3 * BT ? pJ[e] : pI[(d - 3 * BT) & 3][e];
         const T ro = rzo_s[e], rn = sh_s[e][0];
         const bool drop = ro <= min_float;  // :79, per column
         const T beta = drop ? (T)0 : rn / ro;
-        dst[l] = drop ? dv[s][0] : mgp_fma(beta, dst[l], dv[s][0]);  // a select, not 0 * p
+        dst[l] = drop ? dv[s] : mgp_fma(beta, dst[l], dv[s]);  // a select, not 0 * p
       }
     }
     lds_barrier();
@@ -1525,37 +1310,28 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
       // own vector is served before the slowest producer's store has landed and costs a second round trip
       if (w < 2 * BT) {
         const int e = w >> 1;
-        T sl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp[4] = {0, 0, 0, 0};
-        bool ok = false;
-        for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
-        for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
-          bool mine = true;
-          if ((w & 1) == 0) {
+        const bool slots = (w & 1) == 0;
+        T val[8];
+        int vo[8], so[8];
+        bool need[8];
 #pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2)
-              if (i2 < R && ook)
-                mine = Gran<T>::load(grs, pb.Qg + ((long)e * qstride + ((long)J * R + i2) * TS + l + kz) * W, ea, sl[i2]) && mine;
-          } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              if (m * 64 + l < nact)
-                mine = Gran<T>::load(grs, pb.wpg + ((long)e * 256 + m * 64 + l + kz) * W, ea, tp[m]) && mine;
-          }
-          ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
-          if (!ok) __builtin_amdgcn_s_sleep(2);
+        for (int i2 = 0; i2 < 8; ++i2) {
+          const bool act = slots ? i2 < R : i2 < 4;
+          need[i2] = act && (slots ? ook : i2 * 64 + l < nact);
+          so[i2] = !act ? 0 : (slots ? (e * (int)qstride + (J * R + i2) * TS) * GB : wpg_off + (e * 256 + i2 * 64) * GB);
+          vo[i2] = l * GB + kzi;
         }
+        for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
+        const bool ok = poll_units<T, 8>(grs, vo, so, need, ea, val);
         if (!ok && l == 0) fail_s = 1;
-        if ((w & 1) == 0) {
-          T ap = 0;
+        T acc = 0;  // row groups / blocks of 64 workgroups in order
 #pragma unroll
-          for (int i2 = 0; i2 < 8; ++i2) ap += sl[i2];  // row groups in order
-          apOwn[e][l] = ap;
+        for (int i2 = 0; i2 < 8; ++i2) acc += val[i2];
+        if (slots) {
+          apOwn[e][l] = acc;
         } else {
-          T d = 0;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) d += tp[m];
-          d = wave_allsum_valu(d);
-          if (l == 0) sh_s[e][2] = d;
+          acc = wave_allsum_valu(acc);
+          if (l == 0) sh_s[e][2] = acc;
         }
       }
       __syncthreads();
@@ -1669,16 +1445,15 @@ static bool d1_blk_geometry(const mgp_handle* h, long nt, int* S) {
   *S = (int)s;
   return true;
 }
-// which register-resident form a solve takes: 1 = full matrix, 2 = super-blocks, 3 = round-robin triangle, 0 = none
-// (MGP_CG_DENSE1: 3 = the best form, 4 = no full-matrix form, 5 = the round-robin triangle only)
+// which register-resident form a solve takes: 1 = full matrix, 2 = super-blocks of the triangle, 0 = none
+// (MGP_CG_DENSE1: 3 = full matrix where it fits, 4 = super-blocks wherever they fit)
 static int d1_persist_form(const mgp_handle* h, long n, long bt) {
-  const long nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
-  const int G = d1_persist_grid(h);
+  const long nt = (n + 63) / 64;
   if (h->cg_dense1 < 3 || !mgp_dense1_eligible(h, n) || bt < 1 || bt > 8) return 0;
   int R = 0, rpg = 0, S = 0;
   if (h->cg_dense1 == 3 && d1_full_geometry(h, nt, &R, &rpg)) return 1;
-  if (h->cg_dense1 <= 4 && bt <= 6 && d1_blk_geometry(h, nt, &S)) return 2;
-  if (bt == 1 && nt <= 64 && nt <= G && ntiles <= 9L * G) return 3;
+  if (bt <= 6 && d1_blk_geometry(h, nt, &S)) return 2;
+  if (d1_full_geometry(h, nt, &R, &rpg)) return 1;
   return 0;
 }
 bool mgp_dense1_persist_eligible(const mgp_handle* h, int64_t n, int64_t bt) { return d1_persist_form(h, n, bt) != 0; }
@@ -1821,13 +1596,6 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
       MGP_D1BB(TT, JV);                                                                                             \
       break;                                                                                                        \
     }                                                                                                               \
-  MGP_HIP(h, hipFuncSetAttribute((const void*)d1_persist_kernel<TT, JV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)(3 * 64 * 64 * sizeof(TT))));                                                  \
-  hipLaunchKernelGGL((d1_persist_kernel<TT, JV>), grid, dim3(768), 3 * 64 * 64 * sizeof(TT), h->stream, st->ctrl,     \
-                     d1_pbuf<TT>(st),                                                                                \
-                     (const TT*)st->A, (long)st->n, st->nt, st->ntiles, (TT*)st->r, (TT*)st->V, (const TT*)st->dinv,   \
-                     (TT*)st->cpart, (const int2*)st->tab, (TT)st->thr, (TT)st->min_float, st->max_it,               \
-                     h->d1_first_poll_sleep, trace);                                                                 \
   } while (0)
   if (st->dtype == MGP_F64) {
     if (st->dinv) MGP_D1P(double, true);
@@ -1849,7 +1617,7 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     (void)hipFree(trace);
     if (FILE* f = fopen(trace_path, "a")) {
       fprintf(f, "# n=%ld: 100 MHz ticks relative to the workgroup's first stamp; columns: top, B read, p formed, tiles "
-                 "done and published, -, A read (owner), slots summed (owner), B published (owner)\n", (long)st->n);
+                 "done and published, own poll done (owner), A read (owner), first column's tiles done, B published (owner)\n", (long)st->n);
       for (int wg = 0; wg < 2; ++wg)
         for (int it = 0; it < 64; ++it) {
           const unsigned long long* e = &host[((size_t)wg * 64 + it) * 8];

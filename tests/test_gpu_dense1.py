@@ -234,8 +234,43 @@ def test_several_columns_on_the_tile_scheme(n, Bt):
         assert relerr(sj, o_sj) < 1e-9
 
 
+@pytest.mark.parametrize("n,Bt", [(2049, 1), (2500, 4), (3000, 6), (3520, 2), (4001, 3), (4095, 5), (4096, 6)])
+def test_super_block_form(n, Bt):
+    """2048 < n <= 4096, 1..6 columns: the whole solve in one launch with the upper triangle on the chip in 3 x 3
+    super-blocks of tiles (csrc/cg_dense1.hip, d1_persist_blk_kernel): whole and ragged sizes (n % 64, nt % 3 != 0),
+    columns of very different size, fp64 and fp32, Jacobi with an initial solution -- k steps against the oracle --
+    and a converged solve on the true residual."""
+    from cggp.conjugate_gradient import JacobiPreconditioner, conjugate_gradient
+    A, _ = problem(n, seed=3 * n + Bt)
+    rng = np.random.default_rng(n + Bt)
+    rhs = rng.standard_normal((Bt, n)) * (10.0 ** rng.integers(-2, 3, (Bt, 1)))
+    for k in (1, 2, 9):
+        sol, (steps, err) = conjugate_gradient(T(A), T(rhs), None, 0.0, max_iterations=k, max_steps_cycle=k + 1)
+        o_sol, (o_steps, o_err) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), 0.0, max_iterations=k,
+                                                         max_steps_cycle=k + 1)
+        assert int(steps) == k == o_steps
+        for b in range(Bt):
+            assert relerr(sol[b], o_sol[b]) < 1e-9, (k, b)
+            assert abs(float(err[b]) - float(o_err[b, 0])) / float(o_err[b, 0]) < 1e-8
+    again, _ = conjugate_gradient(T(A), T(rhs), None, 0.0, max_iterations=9, max_steps_cycle=10, check_every=4)
+    assert torch.equal(sol, again)
+    v0 = 0.01 * rng.standard_normal((Bt, n))
+    sj, (kj, ej) = conjugate_gradient(T(A), T(rhs), T(v0), 0.0, JacobiPreconditioner(), max_iterations=4, max_steps_cycle=5)
+    o_sj, _ = ocg.conjugate_gradient(A, rhs, v0, 0.0, ocg.JacobiPreconditioner(), max_iterations=4, max_steps_cycle=5)
+    assert relerr(sj, o_sj) < 1e-9
+    s32, (k32, _) = conjugate_gradient(T(A, torch.float32), T(rhs, torch.float32), None, 0.0, max_iterations=3,
+                                       max_steps_cycle=4)
+    o32, _ = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), 0.0, max_iterations=3, max_steps_cycle=4)
+    assert int(k32) == 3 and relerr(s32, o32) < 5e-3
+    thr = 1e-9
+    s, (ks, es) = conjugate_gradient(T(A), T(rhs), None, thr, max_iterations=n, max_steps_cycle=n + 1, check_every=16)
+    res = rhs - s.cpu().numpy() @ A
+    assert int(ks) < n and np.all(0.5 * np.sum(res * res, axis=1) <= thr * (1 + 1e-6) + 1e-16)
+
+
 def test_every_form_of_the_dense_cg_gives_the_oracle_steps():
-    """The forms are chosen when the handle is made (MGP_CG_DENSE1 = 3: register-resident for n <= 4096, 1: two launches
+    """The forms are chosen when the handle is made (MGP_CG_DENSE1 = 3: register-resident for n <= 4096 -- the full
+    matrix for n <= 2048, super-blocks of the triangle above; 4: super-blocks wherever they fit; 1: two launches
     per iteration; MGP_CG_DENSE1_COLS = 1: several columns through the skinny product as in round 3): the stress
     script -- random n, steps, Jacobi, initial solutions, fp32, each case against the several-column kernels -- and a
     k-step comparison with the oracle, once per form, each in a process of its own."""
@@ -254,8 +289,8 @@ def test_every_form_of_the_dense_cg_gives_the_oracle_steps():
         "    o, _ = ocg.conjugate_gradient(A, b, np.zeros((Bt, n)), 0.0, max_iterations=6, max_steps_cycle=7)\n"
         "    assert int(k) == 6 and np.max(np.abs(s.cpu().numpy() - o)) / np.max(np.abs(o)) < 1e-9, (n, Bt)\n"
         "print('FORM_OK')\n" % (root, os.path.join(root, "conjugate-gradient-sparse-gp_amd")))
-    for env in ({"MGP_CG_DENSE1": "1"}, {"MGP_CG_DENSE1": "3"}, {"MGP_CG_DENSE1_COLS": "1"}, {"MGP_CG_DENSE1_COLS": "8"},
-                {"MGP_CG_DENSE1": "0"},
+    for env in ({"MGP_CG_DENSE1": "1"}, {"MGP_CG_DENSE1": "3"}, {"MGP_CG_DENSE1": "4"}, {"MGP_CG_DENSE1_COLS": "1"},
+                {"MGP_CG_DENSE1_COLS": "8"}, {"MGP_CG_DENSE1": "0"},
                 {"MGP_CG_PIPELINE_POLLS": "0", "MGP_CG_DENSE1": "1"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
                              timeout=600)
