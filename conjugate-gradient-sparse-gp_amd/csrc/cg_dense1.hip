@@ -753,23 +753,33 @@ __device__ __forceinline__ bool poll_units_fn(const GranRs& R, VoFn vo, SoFn so,
   return ok;
 }
 
+// one round of a poll's loads / its tag tests (see poll_units).  The scheduler must not interleave the loads with the
+// tag tests either (it does, to save registers): no load moves below the `memory` statement, no use of a loaded value
+// above the statements that name it
+template <typename T, int U>
+__device__ __forceinline__ void poll_issue(const GranRs& R, const int (&vo)[U], const int (&so)[U],
+                                           typename Gran<T>::Raw (&raw)[U]) {
+#pragma unroll
+  for (int i = 0; i < U; ++i) raw[i] = Gran<T>::raw(R, vo[i], __builtin_amdgcn_readfirstlane(so[i]));
+  asm volatile("" ::: "memory");
+}
+template <typename T, int U>
+__device__ __forceinline__ bool poll_test(typename Gran<T>::Raw (&raw)[U], const bool (&need)[U], unsigned epoch, T (&val)[U]) {
+#pragma unroll
+  for (int i = 0; i < U; ++i) asm volatile("" : "+v"(raw[i]));
+  bool mine = true;
+#pragma unroll
+  for (int i = 0; i < U; ++i) mine = mine & (Gran<T>::unpack(raw[i], epoch, val[i]) | !need[i]);
+  return __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+}
 template <typename T, int U>
 __device__ __forceinline__ bool poll_units(const GranRs& R, const int (&vo)[U], const int (&so)[U], const bool (&need)[U],
                                            unsigned epoch, T (&val)[U]) {
   bool ok = false;
   for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
     typename Gran<T>::Raw raw[U];
-#pragma unroll
-    for (int i = 0; i < U; ++i) raw[i] = Gran<T>::raw(R, vo[i], __builtin_amdgcn_readfirstlane(so[i]));
-    // ... and the scheduler must not interleave them with the tag tests either (it does, to save registers): no load
-    // moves below the first statement, no use of a loaded value above the ones after it
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < U; ++i) asm volatile("" : "+v"(raw[i]));
-    bool mine = true;
-#pragma unroll
-    for (int i = 0; i < U; ++i) mine = mine & (Gran<T>::unpack(raw[i], epoch, val[i]) | !need[i]);
-    ok = __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+    poll_issue<T, U>(R, vo, so, raw);
+    ok = poll_test<T, U>(raw, need, epoch, val);
     if (!ok) __builtin_amdgcn_s_sleep(2);
   }
 #pragma unroll
