@@ -15,6 +15,7 @@
 // batch.  Vectors are [Bt, n] row-major (the function-level layout, :24-32); one workgroup owns
 // one right-hand side, dot products are wavefront shuffles + one LDS hop.
 #include <chrono>
+#include <cstdio>
 
 #include "mgp_common.h"
 
@@ -803,6 +804,8 @@ extern "C" int mgp_pcg_solve(mgp_handle* h, const mgp_operator* op, const mgp_pr
     if (V0 != nullptr && V0 == V_out)
       return mgp_fail(h, MGP_E_HIP, "dense CG: a hand-off between resident workgroups timed out (is the GPU shared?) and "
                                     "the initial solution was overwritten in place; set MGP_CG_DENSE1=1");
+    fprintf(stderr, "libmgp: dense CG: a hand-off between resident workgroups timed out (is the GPU shared?); this solve "
+                    "runs again with two launches per iteration\n");
     h->d1_persist_off = true;  // the solve again, from its inputs, two launches per iteration
     rc = run();
     h->d1_persist_off = false;

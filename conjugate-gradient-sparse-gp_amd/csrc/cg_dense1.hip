@@ -853,7 +853,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
                                                              const T* __restrict__ A, long n, int nt, int S,
                                                              T* __restrict__ r, T* __restrict__ v,
                                                              const T* __restrict__ dinv, T* __restrict__ cpart, T thr,
-                                                             T min_float, int max_it, int first_poll_sleep,
+                                                             T min_float, int max_it, int first_poll_sleep, int absent_wg,
                                                              unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
@@ -875,6 +875,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   };
   const int nblk = S * (S + 1) / 2;
   if (me >= nblk) return;  // the rest of the grid leaves at once
+  if (me == absent_wg) return;  // fault injection (MGP_D1_INJECT_ABSENT): a workgroup that is not there -- the others must time out, not hang
   int SI = 0, SJ = me;     // row-major over the upper triangle of super-blocks
   while (SJ >= S - SI) {
     SJ -= S - SI;
@@ -1175,7 +1176,7 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
                                                               const T* __restrict__ A, long n, int nt, int R, int rpg,
                                                               T* __restrict__ r, T* __restrict__ v,
                                                               const T* __restrict__ dinv, T* __restrict__ cpart,
-                                                              T thr, T min_float, int max_it, int first_poll_sleep,
+                                                              T thr, T min_float, int max_it, int first_poll_sleep, int absent_wg,
                                                               unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
@@ -1190,6 +1191,7 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
   };
   const int nact = nt * R;  // workgroups with tiles; the rest of the grid leaves at once
   if (me >= nact) return;
+  if (me == absent_wg) return;  // fault injection, see d1_persist_blk_kernel
   const int J = me / R, rg = me - J * R;
   const int I = rg * rpg + q;               // tile row of this group
   const bool have = q < rpg && I < nt;      // uniform per group
@@ -1564,7 +1566,7 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     hipLaunchKernelGGL((d1_persist_blk_kernel<TT, JV, BTV>), grid, dim3(768), dyn, h->stream, st->ctrl,                \
                        d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Sb, (TT*)st->r, (TT*)st->V,            \
                        (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
-                       h->d1_first_poll_sleep, trace);                                                               \
+                       h->d1_first_poll_sleep, h->d1_inject_absent, trace);                                                               \
   } while (0)
 #define MGP_D1BB(TT, JV)                     \
   switch (st->bt) {                          \
@@ -1583,7 +1585,7 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     hipLaunchKernelGGL((d1_persist_full_kernel<TT, JV, BTV>), grid, dim3(1024), dyn, h->stream, st->ctrl,              \
                        d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Rg, rpg, (TT*)st->r, (TT*)st->V,       \
                        (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
-                       h->d1_first_poll_sleep, trace);                                                               \
+                       h->d1_first_poll_sleep, h->d1_inject_absent, trace);                                                               \
   } while (0)
 #define MGP_D1FB(TT, JV)                     \
   switch (st->bt) {                          \

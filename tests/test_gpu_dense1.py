@@ -300,6 +300,36 @@ def test_every_form_of_the_dense_cg_gives_the_oracle_steps():
     assert out.returncode == 0 and "cases ok" in out.stdout, out.stderr[-1500:]
 
 
+@pytest.mark.parametrize("n,Bt,absent", [(4096, 1, 3), (3000, 5, 0), (2048, 1, 17), (1536, 4, 2)])
+def test_a_missing_workgroup_makes_the_register_resident_solve_fail_over_not_hang(n, Bt, absent):
+    """The register-resident forms need every workgroup on the chip at once.  MGP_D1_INJECT_ABSENT=<w> makes workgroup
+    w leave at launch -- what a shared GPU would look like: every wait of the others is bounded, the launch ends with
+    its error word set, libmgp says so on stderr and runs the solve again with two launches per iteration; the result
+    is the oracle's.  (An owner, a workgroup without a chunk, both forms, one and several columns.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+        "from oracle import cg as ocg\n"
+        "from cggp.conjugate_gradient import conjugate_gradient\n"
+        "n, Bt = %d, %d\n"
+        "rng = np.random.default_rng(9)\n"
+        "Q = rng.standard_normal((n, 16)); A = Q @ Q.T / 16 + np.diag(0.5 + rng.random(n)); b = rng.standard_normal((Bt, n))\n"
+        "t0 = time.time()\n"
+        "s, (k, e) = conjugate_gradient(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), None, 0.0, max_iterations=6, max_steps_cycle=7)\n"
+        "torch.cuda.synchronize(); dt = time.time() - t0\n"
+        "o, _ = ocg.conjugate_gradient(A, b, np.zeros((Bt, n)), 0.0, max_iterations=6, max_steps_cycle=7)\n"
+        "assert int(k) == 6 and np.max(np.abs(s.cpu().numpy() - o)) / np.max(np.abs(o)) < 1e-9\n"
+        "assert dt < 30.0, dt\n"
+        "print('FAILOVER_OK %%.2f s' %% dt)\n" % (root, os.path.join(root, "conjugate-gradient-sparse-gp_amd"), n, Bt))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MGP_D1_INJECT_ABSENT=str(absent)),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "FAILOVER_OK" in out.stdout, out.stderr[-1500:]
+    assert "hand-off between resident workgroups timed out" in out.stderr, out.stderr[-1500:]
+
+
 def test_fp32():
     from cggp.conjugate_gradient import conjugate_gradient
     n = 2048
