@@ -56,6 +56,7 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   if (tf) h->tri_form = atoi(tf);
   const char* fa = getenv("MGP_FUSE_AGREE");
   if (fa) h->fuse_agree = atoi(fa);
+  if (getenv("MGP_SGPR_KMM_ASIDE")) h->kmm_aside = atoi(getenv("MGP_SGPR_KMM_ASIDE"));
   const char* kta = getenv("MGP_KDENSE_TA");
   if (kta && (atoi(kta) == 16 || atoi(kta) == 64)) h->kdense_ta = atoi(kta);
   const char* cd1 = getenv("MGP_CG_DENSE1");
@@ -141,6 +142,9 @@ extern "C" int mgp_destroy(mgp_handle* h) {
   if (h->host_flag) (void)hipHostFree(h->host_flag);
   for (auto& e : h->poll_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->aside_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->aside_stream) (void)hipStreamDestroy(h->aside_stream);
   if (h->ones) (void)hipFree(h->ones);
   if (h->dparams) (void)hipFree(h->dparams);
   if (h->e2tabs) (void)hipFree(h->e2tabs);

@@ -413,7 +413,39 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       T* u = (T*)h->opws;
       // the collective works on the caller's buffer when one is given; single rank: straight into out
       T* tt = coll ? (op->partial_buf ? (T*)op->partial_buf : u + Bt * N) : out;
-      if (N > 0) {
+      long rb = op->kmm_row_begin, re = op->kmm_row_end;
+      if (rb == 0 && re == 0) re = M;  // unset: this rank owns every row of Kmm
+      bool word_written = false;
+      // One right-hand side: this rank's slab of Kmm.p does not depend on the sweeps -- it goes to a stream of its own,
+      // forked when p is ready, and comes back as the addend of the K_mn sweep: 31 us of HBM streaming at M = 4096
+      // beside 2.3 ms of vector-ALU-bound sweep instead of behind it
+      // (worth its two events from ~50 MB of slab on: one rank's share of 8 at M = 4096 is 17 MB = 4 us, measured 5 us slower)
+      const bool aside = Bt == 1 && N > 0 && re > rb &&
+                         (h->kmm_aside > 1 || (h->kmm_aside == 1 && (size_t)(re - rb) * M * sizeof(T) >= ((size_t)48 << 20)));
+      if (aside) {
+        if (!h->aside_stream) MGP_HIP(h, hipStreamCreateWithFlags(&h->aside_stream, hipStreamNonBlocking));
+        for (int e = 0; e < 2; ++e)
+          if (!h->aside_ev[e]) MGP_HIP(h, hipEventCreateWithFlags(&h->aside_ev[e], hipEventDisableTiming));
+        T* kmp = u + Bt * N + Bt * M + 2;
+        hipStream_t main_stream = h->stream;
+        MGP_HIP(h, hipEventRecord(h->aside_ev[0], main_stream));
+        MGP_HIP(h, hipStreamWaitEvent(h->aside_stream, h->aside_ev[0], 0));
+        h->stream = h->aside_stream;
+        word_written = coll && h->fuse_agree;  // the slab product also writes this rank's agreement word behind the partial
+        int rc = MGP_OK;
+        if (hipMemsetAsync(kmp, 0, (size_t)M * sizeof(T), h->stream) != hipSuccess) rc = mgp_fail(h, MGP_E_HIP, "memset of Kmm.p failed");
+        if (rc == MGP_OK)
+          rc = mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, 1.0, kmp, gate,
+                                      word_written ? (void*)(tt + Bt * M) : nullptr);
+        h->stream = main_stream;
+        MGP_TRY(rc);
+        MGP_HIP(h, hipEventRecord(h->aside_ev[1], h->aside_stream));
+        MGP_TRY(mgp_sweep(h, op->kernel, op->X, N, op->Z, M, VecView{P, 1, M}, (int)Bt, VecViewMut{u, 1, N}, 0.0,
+                          VecView{nullptr, 0, 0}, gate));
+        MGP_HIP(h, hipStreamWaitEvent(main_stream, h->aside_ev[1], 0));
+        MGP_TRY(mgp_sweep(h, op->kernel, op->Z, M, op->X, N, VecView{u, 1, N}, (int)Bt, VecViewMut{tt, 1, M}, op->s2,
+                          VecView{kmp, 1, M}, gate));
+      } else if (N > 0) {
         MGP_TRY(mgp_sweep(h, op->kernel, op->X, N, op->Z, M, VecView{P, 1, M}, (int)Bt, VecViewMut{u, 1, N}, 0.0,
                           VecView{nullptr, 0, 0}, gate));
         MGP_TRY(mgp_sweep(h, op->kernel, op->Z, M, op->X, N, VecView{u, 1, N}, (int)Bt, VecViewMut{tt, 1, M}, 0.0,
@@ -421,10 +453,9 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
       } else {
         MGP_HIP(h, hipMemsetAsync(tt, 0, (size_t)Bt * M * sizeof(T), h->stream));
       }
-      long rb = op->kmm_row_begin, re = op->kmm_row_end;
-      if (rb == 0 && re == 0) re = M;  // unset: this rank owns every row of Kmm
-      bool word_written = false;
-      if (Bt == 1) {
+      if (aside) {
+        // done above
+      } else if (Bt == 1) {
         // with a collective the slab product also writes this rank's agreement word behind the partial
         word_written = coll && re > rb && h->fuse_agree;
         MGP_TRY(mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, op->s2, tt, gate,

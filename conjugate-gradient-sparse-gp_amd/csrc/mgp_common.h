@@ -48,6 +48,12 @@ struct mgp_handle {
   // pinned host word for the convergence poll
   int* host_flag = nullptr;
   hipEvent_t poll_ev[2] = {nullptr, nullptr};  // one polled batch of the dense one-RHS CG in flight (cg.hip)
+  // SGPR operator, one right-hand side: the s2*Kmm.p slab product runs on a stream of its own beside the K_nm sweep
+  // (it reads Kmm from HBM while the sweep is bound by vector-ALU issue) and enters the K_mn sweep as its addend
+  // (MGP_SGPR_KMM_ASIDE=0: on the solve's stream after both sweeps, as rounds 1-3; 1: for slabs of 48 MB and more; 2: always)
+  int kmm_aside = 1;
+  hipStream_t aside_stream = nullptr;
+  hipEvent_t aside_ev[2] = {nullptr, nullptr};  // fork (p is ready), join (Kmm.p is ready)
   // most right-hand sides the tile scheme takes (MGP_CG_DENSE1_COLS: 1 = one only, as round 3; up to 8); 0 = by size,
   // where it was measured faster than the skinny product + fused update: 4 for n <= 4096, 6 above
   int cg_dense1_cols = 0;

@@ -826,6 +826,22 @@ def test_sgpr_operator_and_cg(name):
     assert relerr(sol5, o_sol5) < 1e-9
 
 
+def test_sgpr_kmm_product_beside_the_sweep_at_small_sizes():
+    """For slabs of Kmm of 48 MB and more the SGPR operator runs its s2*Kmm.p product on a stream of its own beside the
+    K_nm sweep and takes it as the addend of the K_mn sweep (csrc/cg.hip; C3: the whole 134 MB).  MGP_SGPR_KMM_ASIDE=2
+    forces that route at every size: the operator / CG tests above and the rank-sharded solve (row slabs of Kmm, the
+    agreement word written by the slab product) must hold on it unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                          os.path.join(root, "tests", "test_distributed.py"), "-k",
+                          "sgpr_operator_and_cg or sgpr_cg_model or sgpr_solve_paths or sharded_sgpr_cg_on_one_gpu"],
+                         env=dict(os.environ, MGP_SGPR_KMM_ASIDE="2"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
 # ------------------------------------------------------------------ models
 def model_problem(name="se", N=600, D=2, M=40, seed=3):
     rng = np.random.default_rng(seed)
