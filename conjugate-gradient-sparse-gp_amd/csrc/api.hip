@@ -67,6 +67,7 @@ extern "C" int mgp_create(mgp_handle** out, int device) {
   }
   if (getenv("MGP_D1_FIRST_POLL")) h->d1_first_poll_sleep = atoi(getenv("MGP_D1_FIRST_POLL"));
   if (getenv("MGP_D1_INJECT_ABSENT")) h->d1_inject_absent = atoi(getenv("MGP_D1_INJECT_ABSENT"));
+  if (getenv("MGP_D1_OWNER_SPREAD")) h->d1_owner_spread = atoi(getenv("MGP_D1_OWNER_SPREAD"));
   const char* cpp = getenv("MGP_CG_PIPELINE_POLLS");
   if (cpp) h->poll_pipeline = atoi(cpp) != 0;
   const char* tm = getenv("MGP_TRI_MIN_N");

@@ -838,12 +838,9 @@ __global__ __launch_bounds__(64) void d1_persist_seed_kernel(const T* __restrict
 // Qg + e (nt (S + 1) 64) W with slot j of chunk c at ((c (S + 1) + j) 64) W.
 template <typename T, int BT>
 struct D1Blk {
-  static constexpr int kWpc = 12 / BT;                        // owner: polling waves per column
-  static constexpr int kUnits = 23 + 4;                       // <= S + 1 slot vectors + <= 4 x 64 workgroup shares
-  static constexpr int kUpw = (kUnits + kWpc - 1) / kWpc;     // 64-lane loads per polling wave
   static constexpr size_t kTile = (size_t)3 * 64 * 64 * sizeof(T);
   static constexpr size_t kColp = (size_t)3 * 12 * 64 * sizeof(T);  // one column's partial column products
-  static constexpr size_t kStatic = (size_t)(6 * BT + 2 * BT + 1) * 64 * sizeof(T) + 1024;
+  static constexpr size_t kStatic = (size_t)(6 * BT + 2 * 6) * 64 * sizeof(T) + 1536;  // p of six chunks, r / v of <= 6 owned items, small words
   static constexpr int kColBuf = kTile + 2 * kColp + kStatic <= (size_t)160 * 1024 ? 2 : 1;
   static constexpr size_t kDyn = kTile + kColBuf * kColp;
 };
@@ -853,12 +850,12 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
                                                              const T* __restrict__ A, long n, int nt, int S,
                                                              T* __restrict__ r, T* __restrict__ v,
                                                              const T* __restrict__ dinv, T* __restrict__ cpart, T thr,
-                                                             T min_float, int max_it, int first_poll_sleep, int absent_wg,
+                                                             T min_float, int max_it, int first_poll_sleep, int absent_wg, int spread,
                                                              unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
   using Cfg = D1Blk<T, BT>;
-  constexpr int CB = Cfg::kColBuf, WPC = Cfg::kWpc, UPW = Cfg::kUpw;
+  constexpr int CB = Cfg::kColBuf;
   constexpr int GB = Gran<T>::kBytes;  // bytes of an element's granules
   const GranRs grs = make_gran_rs(pb.Qg, pb.bytes);
   const int wpg_off = (int)((const char*)pb.wpg - (const char*)pb.Qg), cg_off = (int)((const char*)pb.cg - (const char*)pb.Qg),
@@ -886,8 +883,10 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   const int I = 3 * SI + g;                       // tile row of this four-wave group
   const long qstride = (long)nt * (S + 1) * TS;   // elements of one column's slot vectors
   __shared__ T pJ[3][BT][TS], pI[3][BT][TS];
-  __shared__ T rOwn[BT][TS], vOwn[BT][TS], dOwn[TS], shOwn[BT][2];
+  constexpr int NI = BT < 6 ? (BT < 2 ? 2 : 2 * ((BT + 1) / 2)) : 6;  // most (chunk, column) items a workgroup can own
+  __shared__ T rOwn[NI][TS], vOwn[NI][TS], shOwn[NI][2];
   __shared__ T dP[12];                  // owner: per polling wave its sum of workgroup shares
+  __shared__ int it_c[NI], it_e[NI], it_p[NI];  // an owned item: chunk, column, where its p lives (3 role + pos)
   __shared__ T gsum[BT][12], csum[BT][3];  // per column: the waves' shares of p.Ap from the row products, the layers' from the column products
   __shared__ T sh_s[BT][3];             // per column: rz, ||r||^2 of the current residual, p.Ap
   __shared__ T rzo_s[BT];               // per column: rz of the previous iteration
@@ -920,31 +919,40 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
       else a2s[16 * wq + q][l] = x;
     }
   }
-  // ---- chunk ownership (see above)
-  int own = -1, opos = 0;
-  bool orole_j = false;
-  if (SJ - SI <= 2) {
-    own = 3 * SI + (SJ - SI);  // p_own = the row chunk g = SJ - SI (in a diagonal block that is column chunk 0 too)
-    opos = SJ - SI;
-  } else if (SI + S - SJ <= 2) {
-    opos = SI + S - SJ;        // wrapped: p_own = the column chunk ly = pos
-    own = 3 * SJ + opos;
-    orole_j = true;
+  // ---- ownership, by (chunk, column): E = min(BT, S / 3) columns of a chunk go to E different workgroups that hold its
+  // p anyway -- (c = 3 s + pos, e) with d = pos + 3 (e mod E) belongs to block (s, s + d) as the row chunk `pos`, or, where
+  // s + d >= S, to block (s + d - S, s) as the column chunk `pos`; columns e, e + E, ... share an owner.  At S = 22 and
+  // BT <= 6 every column of a chunk has an owner of its own and a workgroup owns at most two items: the owners' reads
+  // (S + 1 vectors and the shares per item) and updates spread over up to 64 BT workgroups instead of 64.
+  const T(*pIr)[BT][TS] = diag ? pJ : pI;  // row chunks of a diagonal block ARE its column chunks
+  int nitems = 0;
+  {
+    const int E = !spread ? 1 : (BT < S / 3 ? BT : S / 3), dl = SJ - SI;  // MGP_D1_OWNER_SPREAD=0: all columns of a chunk at one owner
+    if (t == 0) {
+      int ni = 0;
+      if (dl <= 3 * E - 1 && 3 * SI + dl % 3 < nt)
+        for (int e = dl / 3; e < BT; e += E) it_c[ni] = 3 * SI + dl % 3, it_e[ni] = e, it_p[ni] = dl % 3, ++ni;
+      const int dw = S - dl;
+      if (dl > 0 && dw <= 3 * E - 1 && 3 * SJ + dw % 3 < nt)
+        for (int e = dw / 3; e < BT; e += E) it_c[ni] = 3 * SJ + dw % 3, it_e[ni] = e, it_p[ni] = 3 + dw % 3, ++ni;
+      for (int q = ni; q < NI; ++q) it_c[q] = -1, it_e[q] = 0, it_p[q] = 0;
+    }
+    __syncthreads();
+    for (int q = 0; q < NI; ++q) nitems += it_c[q] >= 0 ? 1 : 0;
   }
-  if (own >= nt) own = -1;
-  const long oi = (long)(own >= 0 ? own : 0) * TS + l;
-  const bool ook = own >= 0 && oi < n;
-  if (own >= 0 && w < BT) {  // wave e: column e of the owner's chunk stays on the chip for the whole solve
-    rOwn[w][l] = ook ? r[(long)w * n + oi] : (T)0;
-    vOwn[w][l] = ook ? v[(long)w * n + oi] : (T)0;
-    if (w == 0) dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
+  T dinv_own = 1;    // 1 / diag of the item's chunk: one register pair (LDS is full at six columns)
+  if (w < nitems) {  // wave i: item i stays on the chip for the whole solve
+    const int c = it_c[w], e = it_e[w];
+    const long oi = (long)c * TS + l;
+    const bool ook = oi < n;
+    rOwn[w][l] = ook ? r[(long)e * n + oi] : (T)0;
+    vOwn[w][l] = ook ? v[(long)e * n + oi] : (T)0;
+    if (JAC && ook) dinv_own = dinv[oi];
     if (l == 0) {
-      shOwn[w][0] = cpart[(long)w * 2 * CP + own];
-      shOwn[w][1] = cpart[(long)w * 2 * CP + CP + own];
+      shOwn[w][0] = cpart[(long)e * 2 * CP + c];
+      shOwn[w][1] = cpart[(long)e * 2 * CP + CP + c];
     }
   }
-  const T(*pIr)[BT][TS] = diag ? pJ : pI;                                  // row chunks of a diagonal block ARE its column chunks
-  const T(*ownp)[TS] = orole_j ? pJ[opos] : pIr[opos];                     // [column][element] of p_own
   // duties of the B phase, eight per column e (d = 8 e + j) over the twelve waves: j = 0, 1: the chunks' shares of rz /
   // of ||r||^2; j = 2..4: z of column chunk j - 2 (-> p_J); j = 5..7: z of row chunk j - 5 (-> p_I; none in a diagonal block)
   constexpr int ND = 8 * BT, DPW = (ND + 11) / 12;
@@ -1084,34 +1092,51 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
     }
     stamp(k, 3);
     // ================================================================= the owner's update of iteration k + 1
-    if (own >= 0) {
-      // WPC waves per column read the chunk's S + 1 vectors and the workgroups' shares of p.Ap, all in one round trip.
-      // The first poll waits a little: one issued the moment this workgroup has published is served before the slowest
-      // producer's store has landed and costs a second round trip
+    if (nitems > 0) {
+      // 12 / nitems waves per item read its chunk's S + 1 vectors and the workgroups' shares of p.Ap of its column, all
+      // in one round trip.  The first poll waits a little: one issued the moment this workgroup has published is served
+      // before the slowest producer's store has landed and costs a second round trip
       {
-        const int e = w / WPC, sw = w - e * WPC;
-        if (e < BT) {
-          T val[UPW];
-          // unit u = sw UPW + i: u <= S: slot vector u of the chunk; S < u <= S + 4: 64 of the workgroups' shares
+        const int wpi = 12 / nitems, it = w / wpi, sw = w - it * wpi;  // nitems <= 6
+        if (it < nitems) {
+          const int c = it_c[it], e = it_e[it];
+          const int upw = (S + 5 + wpi - 1) / wpi;  // units of a wave: u = sw upw + i; u <= S: vector u; S < u <= S + 4: 64 shares
+          const bool ook = (long)c * TS + l < n;
           auto so_fn = [&](int i, int z) {
-            const int u = sw * UPW + i + z, m = (u - S - 1) * 64;
-            return u <= S ? (e * (int)qstride + (own * (S + 1) + u) * TS) * GB : (u <= S + 4 ? wpg_off + (e * 256 + m) * GB : 0);
+            const int u = sw * upw + i + z, m = (u - S - 1) * 64;
+            return (i < upw && u <= S) ? (e * (int)qstride + (c * (S + 1) + u) * TS) * GB
+                                       : ((i < upw && u <= S + 4) ? wpg_off + (e * 256 + m) * GB : 0);
           };
           auto vo_fn = [&](int, int z) { return (l + z) * GB; };
           auto need_fn = [&](int i, int z) {
-            const int u = sw * UPW + i + z, m = (u - S - 1) * 64;
-            return u <= S ? ook : (u <= S + 4 && m + l < nblk);
+            const int u = sw * upw + i + z, m = (u - S - 1) * 64;
+            return i < upw && (u <= S ? ook : (u <= S + 4 && m + l < nblk));
           };
           for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
-          const bool ok = poll_units_fn<T, UPW>(grs, vo_fn, so_fn, need_fn, ea, val);
+          T ap = 0, d = 0;  // in index order
+          bool ok;
+          auto sums = [&](auto& val, int U) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+              if (sw * upw + i <= S) ap += val[i];
+              else d += val[i];
+            }
+          };
+          if (upw <= 5) {  // one or two items: 27 units over 12 or 6 waves
+            T val[5];
+            ok = poll_units_fn<T, 5>(grs, vo_fn, so_fn, need_fn, ea, val);
+            sums(val, 5);
+          } else if (upw <= 9) {  // three or four items
+            T val[9];
+            ok = poll_units_fn<T, 9>(grs, vo_fn, so_fn, need_fn, ea, val);
+            sums(val, 9);
+          } else {  // five or six items: two waves each
+            T val[14];
+            ok = poll_units_fn<T, 14>(grs, vo_fn, so_fn, need_fn, ea, val);
+            sums(val, 14);
+          }
           if (!ok && l == 0) fail_s = 1;
           stamp(k, 4);
-          T ap = 0, d = 0;  // in index order
-#pragma unroll
-          for (int i = 0; i < UPW; ++i) {
-            if (sw * UPW + i <= S) ap += val[i];
-            else d += val[i];
-          }
           apP[w][l] = ap;
           d = wave_allsum_valu(d);
           if (l == 0) dP[w] = d;
@@ -1120,39 +1145,44 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
       __syncthreads();
       if (fail_s) break;
       stamp(k, 5);
-      if (w < BT) {  // wave e: column e
+      if (w < nitems) {  // wave i: item i
+        const int wpi = 12 / nitems, c = it_c[w], e = it_e[w], ip = it_p[w];
+        const long oi = (long)c * TS + l;
+        const bool ook = oi < n;
         T ap = 0, d = 0;  // the polling waves in order
-#pragma unroll
-        for (int sw = 0; sw < WPC; ++sw) {
-          ap += apP[w * WPC + sw][l];
-          d += dP[w * WPC + sw];
+        for (int sw = 0; sw < wpi; ++sw) {
+          ap += apP[w * wpi + sw][l];
+          d += dP[w * wpi + sw];
         }
-        const T gamma = (d <= min_float) ? (T)0 : sh_s[w][0] / d;  // :66-68 (rz of the residual the direction came from)
+        const T gamma = (d <= min_float) ? (T)0 : sh_s[e][0] / d;  // :66-68 (rz of the residual the direction came from)
         const T rc = mgp_fma(-gamma, ap, rOwn[w][l]);              // :76
-        const T zn = JAC ? rc * dOwn[l] : rc;                      // :77
-        if (ook) Gran<T>::store(grs, pb.zg + ((long)w * n + oi + kz) * W, ea + 1u, zn);
+        const T zn = JAC ? rc * dinv_own : rc;                     // :77
+        if (ook) Gran<T>::store(grs, pb.zg + ((long)e * n + oi + kz) * W, ea + 1u, zn);
         const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
         if (l == 0) {
-          Gran<T>::store(grs, pb.cg + ((long)w * 128 + own + kz) * W, ea + 1u, prz);
-          Gran<T>::store(grs, pb.cg + ((long)w * 128 + 64 + own + kz) * W, ea + 1u, prr);
+          Gran<T>::store(grs, pb.cg + ((long)e * 128 + c + kz) * W, ea + 1u, prz);
+          Gran<T>::store(grs, pb.cg + ((long)e * 128 + 64 + c + kz) * W, ea + 1u, prr);
           shOwn[w][0] = prz;
           shOwn[w][1] = prr;
         }
         rOwn[w][l] = rc;
-        vOwn[w][l] = mgp_fma(gamma, ownp[w][l], vOwn[w][l]);  // :69
+        const T pown = ip >= 3 ? pJ[ip - 3][e][l] : pIr[ip][e][l];
+        vOwn[w][l] = mgp_fma(gamma, pown, vOwn[w][l]);  // :69
       }
       stamp(k, 7);
     }
     ++k;
   }
-  if (own >= 0 && w < BT) {
-    if (ook) {
-      v[(long)w * n + oi] = vOwn[w][l];
-      r[(long)w * n + oi] = rOwn[w][l];
+  if (w < nitems) {
+    const int c = it_c[w], e = it_e[w];
+    const long oi = (long)c * TS + l;
+    if (oi < n) {
+      v[(long)e * n + oi] = vOwn[w][l];
+      r[(long)e * n + oi] = rOwn[w][l];
     }
     if (l == 0) {
-      cpart[(long)w * 2 * CP + own] = shOwn[w][0];
-      cpart[(long)w * 2 * CP + CP + own] = shOwn[w][1];
+      cpart[(long)e * 2 * CP + c] = shOwn[w][0];
+      cpart[(long)e * 2 * CP + CP + c] = shOwn[w][1];
     }
   }
   if (fail_s && t == 0) *pb.err = 1;
@@ -1566,7 +1596,7 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     hipLaunchKernelGGL((d1_persist_blk_kernel<TT, JV, BTV>), grid, dim3(768), dyn, h->stream, st->ctrl,                \
                        d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Sb, (TT*)st->r, (TT*)st->V,            \
                        (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
-                       h->d1_first_poll_sleep, h->d1_inject_absent, trace);                                                               \
+                       h->d1_first_poll_sleep, h->d1_inject_absent, h->d1_owner_spread, trace);                                                               \
   } while (0)
 #define MGP_D1BB(TT, JV)                     \
   switch (st->bt) {                          \

@@ -59,6 +59,7 @@ struct mgp_handle {
   int cg_dense1_cols = 0;
   int d1_first_poll_sleep = 16;  // register-resident dense CG, owners: x 64 cycles before the first poll of the slots (MGP_D1_FIRST_POLL)
   int d1_inject_absent = -1;  // test only (MGP_D1_INJECT_ABSENT=<workgroup>): that workgroup of the register-resident solve leaves at once
+  int d1_owner_spread = 1;  // super-block form, several columns: the columns of a chunk owned by different workgroups (MGP_D1_OWNER_SPREAD=0: by one)
   bool d1_persist_off = false;  // set for the retry of a solve whose register-resident launch reported a timed-out hand-off
   int poll_pipeline = 1;  // MGP_CG_PIPELINE_POLLS=0: drain the stream at every poll (round 3)
   void* ones = nullptr;  // device constants: double 1.0 at +0, float 1.0f at +8
