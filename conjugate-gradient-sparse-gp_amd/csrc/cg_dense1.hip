@@ -883,7 +883,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   const int I = 3 * SI + g;                       // tile row of this four-wave group
   const long qstride = (long)nt * (S + 1) * TS;   // elements of one column's slot vectors
   __shared__ T pJ[3][BT][TS], pI[3][BT][TS];
-  constexpr int NI = BT < 6 ? (BT < 2 ? 2 : 2 * ((BT + 1) / 2)) : 6;  // most (chunk, column) items a workgroup can own
+  constexpr int NI = BT < 6 ? (BT < 2 ? 2 : 2 * ((BT + 1) / 2)) : 6;  // most (chunk, column) items a workgroup can own (BT > 6: S >= 12, <= 4)
   __shared__ T rOwn[NI][TS], vOwn[NI][TS], shOwn[NI][2];
   __shared__ T dP[12];                  // owner: per polling wave its sum of workgroup shares
   __shared__ int it_c[NI], it_e[NI], it_p[NI];  // an owned item: chunk, column, where its p lives (3 role + pos)
@@ -1021,6 +1021,9 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
 #pragma nounroll
     for (int e = 0; e < BT; ++e) {
       const int cb = CB == 2 ? (e & 1) : 0;
+      // single buffer (7, 8 columns: LDS is full): the sums of column e - 1 must have been read -- waited for HERE, where
+      // nothing is live (after the products it spilled 35 registers)
+      if (CB == 1 && e > 0) lds_barrier();
       const T pj0 = pJ[0][e][l], pj1 = pJ[1][e][l], pj2 = pJ[2][e][l];
       T x[16];
       T cs0 = 0, cs1 = 0, cs2 = 0;
@@ -1041,7 +1044,6 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
         cs1 = mgp_fma(a1[q + 8], pihi, cs1);
         cs2 = mgp_fma(a2hi, pihi, cs2);
       }
-      if (CB == 1 && e > 0) lds_barrier();  // single buffer: the sums of column e - 1 have been read
       // a diagonal tile enters through its row product only
       colp[cb][0][w][l] = (diag && g == 0) ? (T)0 : cs0;
       colp[cb][1][w][l] = (diag && g == 1) ? (T)0 : cs1;
@@ -1494,7 +1496,7 @@ static int d1_persist_form(const mgp_handle* h, long n, long bt) {
   if (h->cg_dense1 < 3 || !mgp_dense1_eligible(h, n) || bt < 1 || bt > 8) return 0;
   int R = 0, rpg = 0, S = 0;
   if (h->cg_dense1 == 3 && d1_full_geometry(h, nt, &R, &rpg)) return 1;
-  if (bt <= 6 && d1_blk_geometry(h, nt, &S)) return 2;
+  if (d1_blk_geometry(h, nt, &S) && (bt <= 6 || S >= 12)) return 2;  // 7, 8 columns: at most four owned items per workgroup from S = 12 on
   if (d1_full_geometry(h, nt, &R, &rpg)) return 1;
   return 0;
 }
@@ -1605,7 +1607,9 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     case 3: MGP_D1B(TT, JV, 3); break;       \
     case 4: MGP_D1B(TT, JV, 4); break;       \
     case 5: MGP_D1B(TT, JV, 5); break;       \
-    default: MGP_D1B(TT, JV, 6); break;      \
+    case 6: MGP_D1B(TT, JV, 6); break;       \
+    case 7: MGP_D1B(TT, JV, 7); break;       \
+    default: MGP_D1B(TT, JV, 8); break;      \
   }
 #define MGP_D1F(TT, JV, BTV)                                                                                         \
   do {                                                                                                               \

@@ -234,9 +234,9 @@ def test_several_columns_on_the_tile_scheme(n, Bt):
         assert relerr(sj, o_sj) < 1e-9
 
 
-@pytest.mark.parametrize("n,Bt", [(2049, 1), (2500, 4), (3000, 6), (3520, 2), (4001, 3), (4095, 5), (4096, 6)])
+@pytest.mark.parametrize("n,Bt", [(2049, 1), (2500, 4), (3000, 6), (3520, 2), (4001, 3), (4095, 5), (4096, 6), (4001, 7), (3000, 8)])
 def test_super_block_form(n, Bt):
-    """2048 < n <= 4096, 1..6 columns: the whole solve in one launch with the upper triangle on the chip in 3 x 3
+    """2048 < n <= 4096, 1..8 columns: the whole solve in one launch with the upper triangle on the chip in 3 x 3
     super-blocks of tiles (csrc/cg_dense1.hip, d1_persist_blk_kernel): whole and ragged sizes (n % 64, nt % 3 != 0),
     columns of very different size, fp64 and fp32, Jacobi with an initial solution -- k steps against the oracle --
     and a converged solve on the true residual."""
