@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
                                                               const T* __restrict__ A, long n, int nt, int R, int rpg,
                                                               T* __restrict__ r, T* __restrict__ v,
                                                               const T* __restrict__ dinv, T* __restrict__ cpart,
-                                                              T thr, T min_float, int max_it, int first_poll_sleep, int absent_wg,
+                                                              T thr, T min_float, int max_it, int first_poll_sleep, int absent_wg, int spread,
                                                               unsigned long long* __restrict__ trace) {
   constexpr int TS = 64;
   constexpr int W = Gran<T>::W;
@@ -1227,7 +1227,11 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
   const int J = me / R, rg = me - J * R;
   const int I = rg * rpg + q;               // tile row of this group
   const bool have = q < rpg && I < nt;      // uniform per group
-  const bool owner = rg == 0;               // of chunk J
+  // chunk J, column e belongs to workgroup (J, e mod R): all R row groups of a tile column hold p_J, so the columns'
+  // owners -- their reads of R vectors + the shares, their updates -- are R different workgroups (MGP_D1_OWNER_SPREAD=0:
+  // row group 0 owns every column).  Local item i of this workgroup is column e = e0 + i estep
+  const int e0 = spread ? rg : 0, estep = spread ? R : 1;
+  const int nown = (spread || rg == 0) && e0 < BT ? (BT - e0 + estep - 1) / estep : 0;
   const long qstride = (long)nt * R * TS;   // elements of one column's vectors
   __shared__ T pJ[BT][TS], pI[4][BT][TS];
   extern __shared__ __attribute__((aligned(16))) unsigned char d1f_dyn_lds[];  // colp[BT][4][4][TS]: 8 KB per column in fp64
@@ -1251,13 +1255,14 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
   }
   const long oi = (long)J * TS + l;  // element of chunk J
   const bool ook = oi < n;
-  if (owner && w < BT) {  // wave e: column e of the owner's chunk
-    rOwn[w][l] = ook ? r[(long)w * n + oi] : (T)0;
-    vOwn[w][l] = ook ? v[(long)w * n + oi] : (T)0;
+  if (w < nown) {  // wave i: item i of the owner's chunk
+    const int e = e0 + w * estep;
+    rOwn[w][l] = ook ? r[(long)e * n + oi] : (T)0;
+    vOwn[w][l] = ook ? v[(long)e * n + oi] : (T)0;
     if (w == 0) dOwn[l] = (JAC && ook) ? dinv[oi] : (T)1;
     if (l == 0) {
-      shOwn[w][0] = cpart[(long)w * 2 * CP + J];
-      shOwn[w][1] = cpart[(long)w * 2 * CP + CP + J];
+      shOwn[w][0] = cpart[(long)e * 2 * CP + J];
+      shOwn[w][1] = cpart[(long)e * 2 * CP + CP + J];
     }
   }
   // duties of the B phase, spread over the sixteen waves: duty d < BT: the chunks' shares of rz, column d; < 2 BT: of
@@ -1348,12 +1353,12 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
     }
     stamp(k, 3);
     // ================================================================= the owner's update of iteration k + 1
-    if (owner) {
-      // wave 2 e: the R <= 8 vectors of chunk J, column e; wave 2 e + 1: the workgroups' shares of p.Ap, column e -- all
-      // in the same round trip.  The first poll waits a little: one issued the moment this workgroup has published its
+    if (nown > 0) {
+      // wave 2 i: the R <= 8 vectors of chunk J, column e_i; wave 2 i + 1: the workgroups' shares of p.Ap, column e_i --
+      // all in the same round trip.  The first poll waits a little: one issued the moment this workgroup has published its
       // own vector is served before the slowest producer's store has landed and costs a second round trip
-      if (w < 2 * BT) {
-        const int e = w >> 1;
+      if (w < 2 * nown) {
+        const int it = w >> 1, e = e0 + it * estep;
         const bool slots = (w & 1) == 0;
         T val[8];
         int vo[8], so[8];
@@ -1372,7 +1377,7 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
 #pragma unroll
         for (int i2 = 0; i2 < 8; ++i2) acc += val[i2];
         if (slots) {
-          apOwn[e][l] = acc;
+          apOwn[it][l] = acc;
         } else {
           acc = wave_allsum_valu(acc);
           if (l == 0) sh_s[e][2] = acc;
@@ -1381,34 +1386,36 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
       __syncthreads();
       if (fail_s) break;
       stamp(k, 5);
-      if (w < BT) {  // wave e: column e
-        const T d = sh_s[w][2];
-        const T gamma = (d <= min_float) ? (T)0 : sh_s[w][0] / d;  // :66-68 (rz of the residual the direction came from)
+      if (w < nown) {  // wave i: item i
+        const int e = e0 + w * estep;
+        const T d = sh_s[e][2];
+        const T gamma = (d <= min_float) ? (T)0 : sh_s[e][0] / d;  // :66-68 (rz of the residual the direction came from)
         const T rc = mgp_fma(-gamma, apOwn[w][l], rOwn[w][l]);  // :76
         const T zn = JAC ? rc * dOwn[l] : rc;                   // :77
-        if (ook) Gran<T>::store(grs, pb.zg + ((long)w * n + oi + kz) * W, ea + 1u, zn);
+        if (ook) Gran<T>::store(grs, pb.zg + ((long)e * n + oi + kz) * W, ea + 1u, zn);
         const T prz = wave_allsum_valu(ook ? zn * rc : (T)0), prr = wave_allsum_valu(ook ? rc * rc : (T)0);
         if (l == 0) {
-          Gran<T>::store(grs, pb.cg + ((long)w * 128 + J + kz) * W, ea + 1u, prz);
-          Gran<T>::store(grs, pb.cg + ((long)w * 128 + 64 + J + kz) * W, ea + 1u, prr);
+          Gran<T>::store(grs, pb.cg + ((long)e * 128 + J + kz) * W, ea + 1u, prz);
+          Gran<T>::store(grs, pb.cg + ((long)e * 128 + 64 + J + kz) * W, ea + 1u, prr);
           shOwn[w][0] = prz;
           shOwn[w][1] = prr;
         }
         rOwn[w][l] = rc;
-        vOwn[w][l] = mgp_fma(gamma, pJ[w][l], vOwn[w][l]);  // :69
+        vOwn[w][l] = mgp_fma(gamma, pJ[e][l], vOwn[w][l]);  // :69
       }
       stamp(k, 7);
     }
     ++k;
   }
-  if (owner && w < BT) {
+  if (w < nown) {
+    const int e = e0 + w * estep;
     if (ook) {
-      v[(long)w * n + oi] = vOwn[w][l];
-      r[(long)w * n + oi] = rOwn[w][l];
+      v[(long)e * n + oi] = vOwn[w][l];
+      r[(long)e * n + oi] = rOwn[w][l];
     }
     if (l == 0) {
-      cpart[(long)w * 2 * CP + J] = shOwn[w][0];
-      cpart[(long)w * 2 * CP + CP + J] = shOwn[w][1];
+      cpart[(long)e * 2 * CP + J] = shOwn[w][0];
+      cpart[(long)e * 2 * CP + CP + J] = shOwn[w][1];
     }
   }
   if (fail_s && t == 0) *pb.err = 1;
@@ -1619,7 +1626,7 @@ int mgp_dense1_persist_run(mgp_handle* h, const MgpDense1* st) {
     hipLaunchKernelGGL((d1_persist_full_kernel<TT, JV, BTV>), grid, dim3(1024), dyn, h->stream, st->ctrl,              \
                        d1_pbuf<TT>(st), (const TT*)st->A, (long)st->n, st->nt, Rg, rpg, (TT*)st->r, (TT*)st->V,       \
                        (const TT*)st->dinv, (TT*)st->cpart, (TT)st->thr, (TT)st->min_float, st->max_it,               \
-                       h->d1_first_poll_sleep, h->d1_inject_absent, trace);                                                               \
+                       h->d1_first_poll_sleep, h->d1_inject_absent, h->d1_owner_spread, trace);                                                               \
   } while (0)
 #define MGP_D1FB(TT, JV)                     \
   switch (st->bt) {                          \
