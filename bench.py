@@ -431,6 +431,10 @@ def main():
             cgm.solve_with_stats(KL2, u2)
             ((_, (c2steps, _)), t_cg2) = timed(lambda: cgm.solve_with_stats(KL2, u2))
             it2_us = 1e3 * t_cg2 / max(int(c2steps), 1)
+            probes5_2 = probes5[:M2].contiguous()
+            cgm.solve_with_stats(KL2, probes5_2)
+            ((_, (p52steps, _)), t_p52) = timed(lambda: cgm.solve_with_stats(KL2, probes5_2))
+            p52_us = 1e3 * t_p52 / max(int(p52steps), 1)
             tri2_bytes = esize * (M2 * (M2 + 64) / 2.0)
             d1_form = {"3": "register-resident: the whole solve in one launch, A held on the chip (csrc/cg_dense1.hip): the "
                             "upper triangle in 3 x 3 super-blocks of tiles for 2048 < n <= 4096, the full matrix for "
@@ -452,7 +456,9 @@ def main():
                                        "iteration is bound by two hand-offs between resident workgroups, not by HBM.  "
                                        "Wall time of the whole solve / steps, start-up included"},
                     "cg_c2_size": {"M": M2, "cg_iterations": int(c2steps), "cg_ms": t_cg2, "cg_us_per_iteration": it2_us,
-                                   "equivalent_GBps": tri2_bytes / (it2_us * 1e-6) / 1e9},
+                                   "equivalent_GBps": tri2_bytes / (it2_us * 1e-6) / 1e9,
+                                   "probe5_iterations": int(p52steps), "probe5_ms": t_p52,
+                                   "probe5_us_per_iteration": p52_us},
                     "probe5_cg": {"columns": 5, "iterations": int(p5steps), "ms": t_p5, "us_per_iteration": p5_us,
                                   "note": "the reference's default num_probes = 5 (models.py:286) on Kmm+Lambda: "
                                           "register-resident form with 5 columns (round 3: skinny MFMA product + fused "
