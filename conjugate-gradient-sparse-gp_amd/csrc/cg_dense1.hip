@@ -775,7 +775,13 @@ __device__ __forceinline__ bool poll_test(typename Gran<T>::Raw (&raw)[U], const
 template <typename T, int U>
 __device__ __forceinline__ bool poll_units(const GranRs& R, const int (&vo)[U], const int (&so)[U], const bool (&need)[U],
                                            unsigned epoch, T (&val)[U]) {
-  bool ok = false;
+  // (an idle unit must not read one fixed address -- a thousand waves' idle units on ONE line were a hot spot worth
+  // 2 us per iteration: the callers point it at lane- and wave-distinct elements of z); a wave without any needed unit
+  // does not poll at all
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < U; ++i) any = any | need[i];
+  bool ok = __builtin_amdgcn_ballot_w64(any) == 0;
   for (int spin = 0; !ok && spin < kPersistBudget; ++spin) {
     typename Gran<T>::Raw raw[U];
     poll_issue<T, U>(R, vo, so, raw);
@@ -940,9 +946,18 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
     __syncthreads();
     for (int q = 0; q < NI; ++q) nitems += it_c[q] >= 0 ? 1 : 0;
   }
+  // a wave's part in the owner phase, as scalars for the whole solve: it polls for item p_it (units from p_sw on) and
+  // updates item w
+  const int wpi = (BT == 1 || nitems == 0) ? 12 : 12 / nitems;  // polling waves per item; nitems <= 6 (one column: <= 1)
+  const int p_it = BT == 1 ? 0 : w / wpi, p_sw = w - p_it * wpi;
+  const int p_c = __builtin_amdgcn_readfirstlane(p_it < nitems ? it_c[p_it] : 0),
+            p_e = __builtin_amdgcn_readfirstlane(p_it < nitems ? it_e[p_it] : 0);
+  const int u_c = __builtin_amdgcn_readfirstlane(w < nitems ? it_c[w] : 0),
+            u_e = __builtin_amdgcn_readfirstlane(w < nitems ? it_e[w] : 0),
+            u_p = __builtin_amdgcn_readfirstlane(w < nitems ? it_p[w] : 0);
   T dinv_own = 1;    // 1 / diag of the item's chunk: one register pair (LDS is full at six columns)
   if (w < nitems) {  // wave i: item i stays on the chip for the whole solve
-    const int c = it_c[w], e = it_e[w];
+    const int c = u_c, e = u_e;
     const long oi = (long)c * TS + l;
     const bool ook = oi < n;
     rOwn[w][l] = ook ? r[(long)e * n + oi] : (T)0;
@@ -978,8 +993,8 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
         const bool zduty = d < ND && j >= 2 && !(j >= 5 && diag) && c < nt;
         const long el = (long)c * TS + l;
         need[s] = sduty ? l < nt : (zduty && el < n);
-        so[s] = sduty ? cg_off + (e * 128 + 64 * j) * GB : (zduty ? zg_off + e * (int)n * GB : 0);
-        vo[s] = (sduty ? l : (zduty ? (int)(el < n ? el : n - 1) : 0)) * GB + kzi;
+        so[s] = sduty ? cg_off + (e * 128 + 64 * j) * GB : (zduty ? zg_off + e * (int)n * GB : zg_off);
+        vo[s] = (sduty ? l : (zduty ? (int)(el < n ? el : n - 1) : w * TS + l)) * GB + kzi;  // idle: see poll_units
       }
       const bool ok = poll_units<T, DPW>(grs, vo, so, need, eb, dv);
       if (!ok && l == 0) fail_s = 1;
@@ -1099,15 +1114,19 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
       // in one round trip.  The first poll waits a little: one issued the moment this workgroup has published is served
       // before the slowest producer's store has landed and costs a second round trip
       {
-        const int wpi = 12 / nitems, it = w / wpi, sw = w - it * wpi;  // nitems <= 6
-        if (it < nitems) {
-          const int c = it_c[it], e = it_e[it];
-          const int upw = (S + 5 + wpi - 1) / wpi;  // units of a wave: u = sw upw + i; u <= S: vector u; S < u <= S + 4: 64 shares
+        const int it = p_it, sw = p_sw;
+        const int upw = (S + 5 + wpi - 1) / wpi;  // units of a wave: u = sw upw + i; u <= S: vector u; S < u <= S + 4: 64 shares
+        if (it < nitems && sw * upw > S + 4) {  // a wave whose units all lie beyond S + 4 has nothing to read
+          apP[w][l] = 0;
+          if (l == 0) dP[w] = 0;
+        } else if (it < nitems) {
+          const int c = p_c, e = p_e;
           const bool ook = (long)c * TS + l < n;
+          // (an idle unit -- beyond upw or beyond S + 4 -- re-reads the wave's unit 0, the same lines again, never one
+          // fixed address: a thousand waves' idle units on ONE line were a hot spot worth 2 us per iteration)
           auto so_fn = [&](int i, int z) {
-            const int u = sw * upw + i + z, m = (u - S - 1) * 64;
-            return (i < upw && u <= S) ? (e * (int)qstride + (c * (S + 1) + u) * TS) * GB
-                                       : ((i < upw && u <= S + 4) ? wpg_off + (e * 256 + m) * GB : 0);
+            const int ui = sw * upw + i + z, u = (i < upw && ui <= S + 4) ? ui : sw * upw + z, m = (u - S - 1) * 64;
+            return u <= S ? (e * (int)qstride + (c * (S + 1) + u) * TS) * GB : wpg_off + (e * 256 + m) * GB;
           };
           auto vo_fn = [&](int, int z) { return (l + z) * GB; };
           auto need_fn = [&](int i, int z) {
@@ -1124,15 +1143,21 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
               else d += val[i];
             }
           };
-          if (upw <= 5) {  // one or two items: 27 units over 12 or 6 waves
+          // as many loads as the wave has units (27 units at S = 22 over 12 / 6 / 4 / 3 / 2 waves for 1 / 2 / 3 / 4 / 5-6
+          // items): two idle loads per wave beside three needed ones cost 1.5 us per iteration at one column
+          if (BT == 1 || upw <= 3) {  // (which of the forms exist follows from the most items a workgroup can own at this BT)
+            T val[3];
+            ok = poll_units_fn<T, 3>(grs, vo_fn, so_fn, need_fn, ea, val);
+            sums(val, 3);
+          } else if (NI >= 2 && upw <= 5) {
             T val[5];
             ok = poll_units_fn<T, 5>(grs, vo_fn, so_fn, need_fn, ea, val);
             sums(val, 5);
-          } else if (upw <= 9) {  // three or four items
+          } else if (NI >= 3 && upw <= 9) {
             T val[9];
             ok = poll_units_fn<T, 9>(grs, vo_fn, so_fn, need_fn, ea, val);
             sums(val, 9);
-          } else {  // five or six items: two waves each
+          } else {
             T val[14];
             ok = poll_units_fn<T, 14>(grs, vo_fn, so_fn, need_fn, ea, val);
             sums(val, 14);
@@ -1148,13 +1173,25 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
       if (fail_s) break;
       stamp(k, 5);
       if (w < nitems) {  // wave i: item i
-        const int wpi = 12 / nitems, c = it_c[w], e = it_e[w], ip = it_p[w];
+        const int c = u_c, e = u_e, ip = u_p;
         const long oi = (long)c * TS + l;
         const bool ook = oi < n;
-        T ap = 0, d = 0;  // the polling waves in order
-        for (int sw = 0; sw < wpi; ++sw) {
-          ap += apP[w * wpi + sw][l];
-          d += dP[w * wpi + sw];
+        T ap = 0, d = 0;  // the polling waves in order, SB LDS reads in flight at a time (a chain of twelve dependent
+                          // reads cost 0.5 us; twelve at once spill beside many columns)
+        constexpr int SB = BT == 1 ? 12 : 6;
+        for (int s0 = 0; s0 < wpi; s0 += SB) {
+          T a4[SB], d4[SB];
+#pragma unroll
+          for (int q = 0; q < SB; ++q) {
+            const int src = s0 + q < wpi ? w * wpi + s0 + q : 0;
+            a4[q] = apP[src][l];
+            d4[q] = dP[src];
+          }
+#pragma unroll
+          for (int q = 0; q < SB; ++q) {
+            ap += s0 + q < wpi ? a4[q] : (T)0;
+            d += s0 + q < wpi ? d4[q] : (T)0;
+          }
         }
         const T gamma = (d <= min_float) ? (T)0 : sh_s[e][0] / d;  // :66-68 (rz of the residual the direction came from)
         const T rc = mgp_fma(-gamma, ap, rOwn[w][l]);              // :76
@@ -1176,7 +1213,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
     ++k;
   }
   if (w < nitems) {
-    const int c = it_c[w], e = it_e[w];
+    const int c = u_c, e = u_e;
     const long oi = (long)c * TS + l;
     if (oi < n) {
       v[(long)e * n + oi] = vOwn[w][l];
@@ -1294,8 +1331,8 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
         const bool irow = iduty && g2 < rpg && I2 < nt;
         const long el = jduty ? oi : (long)(irow ? I2 : 0) * TS + l;
         need[s] = sduty ? l < nt : ((jduty || irow) && el < n);
-        so[s] = sduty ? cg_off + (e * 128 + (d < BT ? 0 : 64)) * GB : ((jduty || irow) ? zg_off + e * (int)n * GB : 0);
-        vo[s] = (sduty ? l : ((jduty || irow) ? (int)(el < n ? el : n - 1) : 0)) * GB + kzi;
+        so[s] = sduty ? cg_off + (e * 128 + (d < BT ? 0 : 64)) * GB : ((jduty || irow) ? zg_off + e * (int)n * GB : zg_off);
+        vo[s] = (sduty ? l : ((jduty || irow) ? (int)(el < n ? el : n - 1) : w * TS + l)) * GB + kzi;  // idle: see poll_units
       }
       const bool ok = poll_units<T, DPW>(grs, vo, so, need, eb, dv);
       if (!ok && l == 0) fail_s = 1;
@@ -1367,7 +1404,8 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
         for (int i2 = 0; i2 < 8; ++i2) {
           const bool act = slots ? i2 < R : i2 < 4;
           need[i2] = act && (slots ? ook : i2 * 64 + l < nact);
-          so[i2] = !act ? 0 : (slots ? (e * (int)qstride + (J * R + i2) * TS) * GB : wpg_off + (e * 256 + i2 * 64) * GB);
+          so[i2] = !act ? zg_off + w * TS * GB  // idle: see poll_units
+                        : (slots ? (e * (int)qstride + (J * R + i2) * TS) * GB : wpg_off + (e * 256 + i2 * 64) * GB);
           vo[i2] = l * GB + kzi;
         }
         for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
