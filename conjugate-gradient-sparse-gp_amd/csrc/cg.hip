@@ -433,10 +433,14 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
         h->stream = h->aside_stream;
         word_written = coll && h->fuse_agree;  // the slab product also writes this rank's agreement word behind the partial
         int rc = MGP_OK;
-        if (hipMemsetAsync(kmp, 0, (size_t)M * sizeof(T), h->stream) != hipSuccess) rc = mgp_fail(h, MGP_E_HIP, "memset of Kmm.p failed");
-        if (rc == MGP_OK)
-          rc = mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, 1.0, kmp, gate,
-                                      word_written ? (void*)(tt + Bt * M) : nullptr);
+        if (rb == 0 && re == M && !word_written) {  // every row is this rank's: written, not accumulated
+          rc = mgp_symm_gemv_assign(h, op->dtype, op->Kmm, M, P, kmp, gate);
+        } else {
+          if (hipMemsetAsync(kmp, 0, (size_t)M * sizeof(T), h->stream) != hipSuccess) rc = mgp_fail(h, MGP_E_HIP, "memset of Kmm.p failed");
+          if (rc == MGP_OK)
+            rc = mgp_symm_gemv_rows_acc(h, op->dtype, op->Kmm, M, P, rb, re, 1.0, kmp, gate,
+                                        word_written ? (void*)(tt + Bt * M) : nullptr);
+        }
         h->stream = main_stream;
         MGP_TRY(rc);
         MGP_HIP(h, hipEventRecord(h->aside_ev[1], h->aside_stream));

@@ -1435,6 +1435,30 @@ int symm_gemv_rows_t(mgp_handle* h, const T* A, long n, const T* p, long rb, lon
   return MGP_OK;
 }
 
+// out = A p, every row, one right-hand side, nothing accumulated (the SGPR operator's Kmm.p beside the sweep when this
+// rank owns every row: no memset of the target before it)
+int mgp_symm_gemv_assign(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, void* out, const int* gate) {
+  dim3 grid((unsigned)((n + 7) / 8));
+  const bool vec16 = (((uintptr_t)A) % 16) == 0;
+  if (dtype == MGP_F64) {
+    if (vec16 && n % 2 == 0)
+      hipLaunchKernelGGL((symm_gemv_kernel<double, 1, 2>), grid, dim3(256), 0, h->stream, (const double*)A, (long)n,
+                         (const double*)p, 1, (double*)out, gate, 0L, (long)n, 1.0, 0, (double*)nullptr);
+    else
+      hipLaunchKernelGGL((symm_gemv_kernel<double, 1, 1>), grid, dim3(256), 0, h->stream, (const double*)A, (long)n,
+                         (const double*)p, 1, (double*)out, gate, 0L, (long)n, 1.0, 0, (double*)nullptr);
+  } else {
+    if (vec16 && n % 4 == 0)
+      hipLaunchKernelGGL((symm_gemv_kernel<float, 1, 4>), grid, dim3(256), 0, h->stream, (const float*)A, (long)n,
+                         (const float*)p, 1, (float*)out, gate, 0L, (long)n, 1.0f, 0, (float*)nullptr);
+    else
+      hipLaunchKernelGGL((symm_gemv_kernel<float, 1, 1>), grid, dim3(256), 0, h->stream, (const float*)A, (long)n,
+                         (const float*)p, 1, (float*)out, gate, 0L, (long)n, 1.0f, 0, (float*)nullptr);
+  }
+  MGP_LAUNCH_CHECK(h);
+  return MGP_OK;
+}
+
 int mgp_symm_gemv_tri_prepare(mgp_handle* h, int dtype, int64_t n, void** Q, const void** tab) {
   MGP_TRY(tri_prepare(h, mgp_elem(dtype), n, 1));
   *Q = h->ws;

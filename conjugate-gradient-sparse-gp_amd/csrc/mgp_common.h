@@ -356,6 +356,7 @@ int mgp_sweep_mfma_f64(mgp_handle* h, const mgp_kernel* k, const double* A, long
 int mgp_syrk_nt_upper(mgp_handle* h, int dtype, const void* Kt, int64_t n, int64_t K, int64_t ld, void* out,
                       int accumulate, int nz, const int* tile_tab, int ntiles);
 int mgp_mirror_upper(mgp_handle* h, int dtype, void* out, const void* slices, int nz, int64_t n, double scale);
+int mgp_symm_gemv_assign(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, void* out, const int* gate);
 int mgp_symm_gemv_rows_acc(mgp_handle* h, int dtype, const void* A, int64_t n, const void* p, int64_t rb, int64_t re,
                            double alpha, void* out, const int* gate, void* word = nullptr);
 // comm.hip: the operator's all-reduce on the handle's stream (errors land in the handle)
