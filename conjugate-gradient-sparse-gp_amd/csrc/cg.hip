@@ -458,7 +458,7 @@ int apply_operator(mgp_handle* h, const mgp_operator* op, const T* P, long Bt, T
         MGP_HIP(h, hipMemsetAsync(tt, 0, (size_t)Bt * M * sizeof(T), h->stream));
       }
       if (aside) {
-        // done above
+        // Kmm.p is the K_mn sweep's addend already
       } else if (Bt == 1) {
         // with a collective the slab product also writes this rank's agreement word behind the partial
         word_written = coll && re > rb && h->fuse_agree;
