@@ -59,7 +59,12 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 32768 and d["scaling"] == "strong"
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
     assert d["convergence_preconditioned"]["converged"] is True
-    assert d["cdgp_same_size"]["cg_iterations"] > 0
+    c = d["cdgp_same_size"]
+    assert c["cg_iterations"] > 0 and c["cg_us_per_iteration"] > 0 and "register-resident" in c["cg_form"]
+    # the reference's default five probes (models.py:286) and the 64 Hutchinson probes of C3, per iteration
+    assert c["probe5_cg"]["columns"] == 5 and c["probe5_cg"]["us_per_iteration"] > 0
+    assert c["cg_c2_size"]["probe5_us_per_iteration"] > 0
+    assert c["probe_cg"]["columns"] == 64 and 0 < c["probe_cg"]["frac_of_fp64_mfma_peak"] < 1
 
 
 @pytest.mark.gpu
