@@ -298,6 +298,10 @@ def test_every_form_of_the_dense_cg_gives_the_oracle_steps():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_dense1.py"), "40", "7"],
                          env=dict(os.environ, MGP_CG_DENSE1_COLS="1"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "cases ok" in out.stdout, out.stderr[-1500:]
+    # ... and 1..8 columns on the register-resident forms, random sizes, against the oracle
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_dense_cols.py"), "40", "3"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "cases ok" in out.stdout, out.stderr[-1500:]
 
 
 @pytest.mark.parametrize("n,Bt,absent", [(4096, 1, 3), (3000, 5, 0), (2048, 1, 17), (1536, 4, 2)])
