@@ -221,8 +221,10 @@ def test_several_columns_on_the_tile_scheme(n, Bt):
     # a converged solve: the step count is that of the slowest column, every column meets the rule on its TRUE residual
     thr = 1e-8
     s, (ks, es) = conjugate_gradient(T(A), T(rhs), None, thr, max_iterations=n, max_steps_cycle=n + 1, check_every=16)
-    o_s, (o_ks, _) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), thr, max_iterations=n, max_steps_cycle=n + 1)
-    assert int(ks) < n and abs(int(ks) - o_ks) <= max(3, o_ks // 20)
+    assert int(ks) < n
+    if n <= 4096:  # (the oracle's converged several-column solve at n = 8000 is 40 s of numpy per case)
+        o_s, (o_ks, _) = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), thr, max_iterations=n, max_steps_cycle=n + 1)
+        assert abs(int(ks) - o_ks) <= max(3, o_ks // 20)
     res = rhs - s.cpu().numpy() @ A
     assert np.all(0.5 * np.sum(res * res, axis=1) <= thr * (1 + 1e-6) + 1e-16)
     # Jacobi + an initial solution, three steps
