@@ -835,12 +835,13 @@ __global__ __launch_bounds__(64) void d1_persist_seed_kernel(const T* __restrict
 //     as ONE vector per tile column: sum_g A_{I_g J_ly}^T p_{I_g} (diagonal tiles only in the row product);
 //   * chunk c of super-row s therefore collects S + 1 vectors (slot j < s: columns of block (j, s); j = s: rows of
 //     (s, s); s < j < S: rows of (s, j); j = S: columns of the diagonal block (s, s)) instead of nt = 64;
-//   * a further right-hand side costs 96 fused multiply-adds and one reduction per wave: BT <= 6 columns (the
-//     reference's 5 probes, models.py:286, at M = 4096), per column its own recurrence (:64-85) and guards (:68, :79),
-//     `any` over the columns as stopping rule (:59-62).
-// The owner of chunk c = 3 s + pos is a workgroup that holds p_c anyway: block (s, s + pos) (as a row chunk), or, where
-// s + pos >= S, block (s + pos - S, s) (as a column chunk) -- one chunk per workgroup for S >= 6.  Hand-offs, epochs,
-// bounds and fail-over as described above.  Granule arrays per column e: cg + e 128 W, zg + e n W, wpg + e 256 W,
+//   * a further right-hand side costs 96 fused multiply-adds and one reduction per wave: BT <= 8 columns (the
+//     reference's 5 probes, models.py:286, at M = 4096; 7 and 8 from S = 12 on, with one column buffer), per column its
+//     own recurrence (:64-85) and guards (:68, :79), `any` over the columns as stopping rule (:59-62).
+// The owner of chunk c = 3 s + pos (one column) is a workgroup that holds p_c anyway: block (s, s + pos) (as a row
+// chunk), or, where s + pos >= S, block (s + pos - S, s) (as a column chunk) -- one chunk per workgroup for S >= 6; with
+// several columns the owners of a chunk's columns are different such workgroups (see "ownership" in the kernel).
+// Hand-offs, epochs, bounds and fail-over as described above.  Granule arrays per column e: cg + e 128 W, zg + e n W, wpg + e 256 W,
 // Qg + e (nt (S + 1) 64) W with slot j of chunk c at ((c (S + 1) + j) 64) W.
 template <typename T, int BT>
 struct D1Blk {
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   // ---- ownership, by (chunk, column): E = min(BT, S / 3) columns of a chunk go to E different workgroups that hold its
   // p anyway -- (c = 3 s + pos, e) with d = pos + 3 (e mod E) belongs to block (s, s + d) as the row chunk `pos`, or, where
   // s + d >= S, to block (s + d - S, s) as the column chunk `pos`; columns e, e + E, ... share an owner.  At S = 22 and
-  // BT <= 6 every column of a chunk has an owner of its own and a workgroup owns at most two items: the owners' reads
+  // BT <= 7 every column of a chunk has an owner of its own and a workgroup owns at most two items: the owners' reads
   // (S + 1 vectors and the shares per item) and updates spread over up to 64 BT workgroups instead of 64.
   const T(*pIr)[BT][TS] = diag ? pJ : pI;  // row chunks of a diagonal block ARE its column chunks
   int nitems = 0;
