@@ -1398,23 +1398,37 @@ __global__ __launch_bounds__(1024) void d1_persist_full_kernel(MgpCgCtrl* __rest
       if (w < 2 * nown) {
         const int it = w >> 1, e = e0 + it * estep;
         const bool slots = (w & 1) == 0;
-        T val[8];
-        int vo[8], so[8];
-        bool need[8];
-#pragma unroll
-        for (int i2 = 0; i2 < 8; ++i2) {
-          const bool act = slots ? i2 < R : i2 < 4;
-          need[i2] = act && (slots ? ook : i2 * 64 + l < nact);
-          so[i2] = !act ? zg_off + w * TS * GB  // idle: see poll_units
-                        : (slots ? (e * (int)qstride + (J * R + i2) * TS) * GB : wpg_off + (e * 256 + i2 * 64) * GB);
-          vo[i2] = l * GB + kzi;
-        }
         for (int sl0 = 0; sl0 < first_poll_sleep; ++sl0) __builtin_amdgcn_s_sleep(1);
-        const bool ok = poll_units<T, 8>(grs, vo, so, need, ea, val);
-        if (!ok && l == 0) fail_s = 1;
         T acc = 0;  // row groups / blocks of 64 workgroups in order
+        bool ok;
+        if (slots) {  // as many loads as units (idle loads are traffic): R <= 8 vectors ...
+          T val[8];
+          int vo[8], so[8];
+          bool need[8];
 #pragma unroll
-        for (int i2 = 0; i2 < 8; ++i2) acc += val[i2];
+          for (int i2 = 0; i2 < 8; ++i2) {
+            need[i2] = i2 < R && ook;
+            so[i2] = (e * (int)qstride + (J * R + (i2 < R ? i2 : 0)) * TS) * GB;  // (an idle unit re-reads vector 0)
+            vo[i2] = l * GB + kzi;
+          }
+          ok = poll_units<T, 8>(grs, vo, so, need, ea, val);
+#pragma unroll
+          for (int i2 = 0; i2 < 8; ++i2) acc += val[i2];
+        } else {  // ... or four blocks of 64 workgroups' shares
+          T val[4];
+          int vo[4], so[4];
+          bool need[4];
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) {
+            need[i2] = i2 * 64 + l < nact;
+            so[i2] = wpg_off + (e * 256 + i2 * 64) * GB;
+            vo[i2] = l * GB + kzi;
+          }
+          ok = poll_units<T, 4>(grs, vo, so, need, ea, val);
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) acc += val[i2];
+        }
+        if (!ok && l == 0) fail_s = 1;
         if (slots) {
           apOwn[it][l] = acc;
         } else {
