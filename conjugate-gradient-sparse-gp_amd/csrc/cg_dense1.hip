@@ -934,7 +934,8 @@ __global__ __launch_bounds__(768) void d1_persist_blk_kernel(MgpCgCtrl* __restri
   const T(*pIr)[BT][TS] = diag ? pJ : pI;  // row chunks of a diagonal block ARE its column chunks
   int nitems = 0;
   {
-    const int E = !spread ? 1 : (BT < S / 3 ? BT : S / 3), dl = SJ - SI;  // MGP_D1_OWNER_SPREAD=0: all columns of a chunk at one owner
+    // MGP_D1_OWNER_SPREAD=0: all columns of a chunk at one owner (an A/B switch; up to six columns -- seven items do not fit)
+    const int E = (!spread && BT <= 6) ? 1 : (BT < S / 3 ? BT : S / 3), dl = SJ - SI;
     if (t == 0) {
       int ni = 0;
       if (dl <= 3 * E - 1 && 3 * SI + dl % 3 < nt)
