@@ -36,3 +36,25 @@ def test_every_item_has_one_owner_that_holds_its_p():
                                 assert (c, e) not in owned, (S, nt, BT, spread, c, e)
                                 owned[(c, e)] = (SI, SJ)
                     assert len(owned) == nt * BT, (S, nt, BT, spread)
+
+
+def test_every_chunk_collects_its_s_plus_one_vectors_exactly_once():
+    """Block (SI, SJ) publishes, per column, one row vector per tile row 3 SI + g into slot SJ of that chunk and one
+    column vector per tile column 3 SJ + ly into slot SI (slot S from a diagonal block): the owner of a chunk polls
+    slots 0..S, so each must be written by exactly one block."""
+    for S in range(6, 23):
+        for nt in range(3 * S - 2, 3 * S + 1):
+            got = {}
+            for SI in range(S):
+                for SJ in range(SI, S):
+                    for g in range(3):
+                        if 3 * SI + g < nt:
+                            key = (3 * SI + g, SJ)
+                            assert key not in got
+                            got[key] = (SI, SJ)
+                    for ly in range(3):
+                        if 3 * SJ + ly < nt:
+                            key = (3 * SJ + ly, S if SI == SJ else SI)
+                            assert key not in got
+                            got[key] = (SI, SJ)
+            assert set(got) == {(c, j) for c in range(nt) for j in range(S + 1)}, (S, nt)
