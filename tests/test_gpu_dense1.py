@@ -336,6 +336,34 @@ def test_a_missing_workgroup_makes_the_register_resident_solve_fail_over_not_han
     assert "hand-off between resident workgroups timed out" in out.stderr, out.stderr[-1500:]
 
 
+def test_register_resident_solve_beside_a_busy_stream():
+    """The register-resident forms want a whole CU per workgroup.  With another stream keeping the chip busy (large
+    fp64 GEMMs queued on it for ~0.5 s) the solve must still come back with the oracle's steps, by whichever road:
+    its workgroups get their CUs late, or a bounded wait runs out and the solve fails over to two launches per
+    iteration -- never a hang, never a wrong iterate."""
+    import time
+    from cggp.conjugate_gradient import conjugate_gradient
+    n, Bt = 4096, 3
+    A, _ = problem(n, seed=77)
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal((Bt, n))
+    o_sol, _ = ocg.conjugate_gradient(A, rhs, np.zeros((Bt, n)), 0.0, max_iterations=6, max_steps_cycle=7)
+    At, bt = T(A), T(rhs)
+    big = torch.randn(6144, 6144, dtype=torch.float64, device=dev())
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            big2 = big @ big
+    for _ in range(3):  # several solves while the side stream works
+        sol, (steps, err) = conjugate_gradient(At, bt, None, 0.0, max_iterations=6, max_steps_cycle=7)
+        assert int(steps) == 6 and relerr(sol, o_sol) < 1e-9
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 60.0
+    del big2
+
+
 def test_fp32():
     from cggp.conjugate_gradient import conjugate_gradient
     n = 2048
